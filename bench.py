@@ -1,0 +1,278 @@
+#!/usr/bin/env python3
+"""Benchmark of the pose-estimation hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W [--workload decode|render|mse|mse_fused|adam]
+
+N > 1 is launched by torch.distributed.run (one rank per GPU).  Every workload here shards by
+batch with no data-path collective, so each rank processes its own batch of the stated size
+(weak scaling); the only collectives are the barriers and the max-over-ranks of the timing.
+Rank 0 prints ONE JSON line.
+
+Default workload "decode" is BASELINE.json configs[1]: heat-map peak decode of
+1024 x 17 x 64 x 48 float32 maps per step, inputs resident in HBM, rotating over enough
+distinct input buffers (> 512 MB) that the 256 MB Infinity Cache cannot serve the reads.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+import torch
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+import pose_estimation_amd as pe  # noqa: E402
+from pose_estimation_amd import synthetic  # noqa: E402
+
+METRIC = "images/sec @256×192,17kp (infer+train, 1/2/4/8 GPU); decode GB/s vs HBM peak"
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, GB/s
+
+K_JOINTS, H, W = 17, 64, 48
+MAP_BYTES = H * W * 4
+
+
+class Workload:
+    name = ""
+    batch = 0
+    dtype = "f32"
+    bytes_per_step = 0      # algorithmic HBM bytes of one step (= one launch of `kernel`)
+    kernel = ""
+    bound = "hbm"
+
+    def setup(self, device): ...
+    def step(self, i: int): ...
+    def cpu_baseline(self): ...
+
+
+class Decode(Workload):
+    name = "decode_1024x17x64x48_f32"
+    batch = 1024
+    dtype = "f32"
+    kernel = "decode_contig_kernel<12>"
+    # read every map once + 16 B of results per map
+    bytes_per_step = batch * K_JOINTS * (MAP_BYTES + 16)
+    nbuf = 4  # 4 x 214 MB = 856 MB of distinct inputs
+
+    def setup(self, device):
+        g = torch.Generator(device=device).manual_seed(1234 + device.index)
+        self.bufs = []
+        for _ in range(self.nbuf):
+            hm = torch.randn(self.batch, K_JOINTS, H, W, device=device, generator=g) * 0.01
+            pos = torch.randint(0, H * W, (self.batch, K_JOINTS), device=device, generator=g)
+            hm.view(self.batch, K_JOINTS, -1).scatter_(2, pos[..., None], 0.8)
+            self.bufs.append(hm)
+        self.out = (torch.empty(self.batch, K_JOINTS, 2, device=device),
+                    torch.empty(self.batch, K_JOINTS, device=device),
+                    torch.empty(self.batch, K_JOINTS, dtype=torch.int32, device=device))
+
+    def step(self, i):
+        pe.decode(self.bufs[i % self.nbuf], refine=True, out=self.out)
+
+    def cpu_baseline(self):
+        import oracle
+
+        hm = synthetic.decode_heatmaps(self.batch, K_JOINTS, H, W, seed=0)
+        oracle.decode_heatmaps(hm[:64])
+        times = []
+        t_end = time.perf_counter() + 12.0
+        while len(times) < 5 or (time.perf_counter() < t_end and len(times) < 40):
+            t0 = time.perf_counter()
+            oracle.decode_heatmaps(hm)
+            times.append(time.perf_counter() - t0)
+        med = float(np.median(times))
+        return {"value": self.batch / med, "unit": "images/s", "cores": 1, "kind": "port",
+                "sample": f"NumPy oracle, full {self.batch}x{K_JOINTS}x{H}x{W} batch, "
+                          f"median of {len(times)} runs ({med * 1e3:.1f} ms each)"}
+
+
+class Render(Workload):
+    name = "render_1024x17x64x48_f32"
+    batch = 1024
+    kernel = "render_contig_kernel"
+    bytes_per_step = batch * K_JOINTS * (MAP_BYTES + 12 + 4)
+
+    def setup(self, device):
+        self.j = torch.from_numpy(synthetic.joints(self.batch, K_JOINTS, 256, 192)).to(device)
+        self.outs = [torch.empty(self.batch, K_JOINTS, H, W, device=device) for _ in range(4)]
+
+    def step(self, i):
+        pe.render_targets(self.j, H, W, 4.0, 2.0, 6, out=self.outs[i % 4])
+
+    def cpu_baseline(self):
+        import oracle
+
+        j = synthetic.joints(64, K_JOINTS, 256, 192)
+        t0 = time.perf_counter()
+        oracle.render_targets(j, H, W, 4.0, 2.0, 6)
+        dt = time.perf_counter() - t0
+        return {"value": 64 / dt, "unit": "images/s", "cores": 1, "kind": "port",
+                "sample": "NumPy oracle, 64-image batch, one run"}
+
+
+class Mse(Workload):
+    fused = False
+    batch = 1024
+    kernel = "mse_map_kernel"
+
+    def __init__(self):
+        self.name = ("mse_fused" if self.fused else "mse") + "_1024x17x64x48_f32"
+        per_map = (2 if self.fused else 3) * MAP_BYTES
+        self.bytes_per_step = self.batch * K_JOINTS * per_map
+
+    def setup(self, device):
+        g = torch.Generator(device=device).manual_seed(7)
+        self.j = torch.from_numpy(synthetic.joints(self.batch, K_JOINTS, 256, 192)).to(device)
+        self.preds = [torch.randn(self.batch, K_JOINTS, H, W, device=device, generator=g)
+                      for _ in range(3)]
+        self.t, self.w = pe.render_targets(self.j, H, W, 4.0, 2.0, 6)
+        self.ws = pe.mse_workspace(self.batch, K_JOINTS, device)
+
+    def step(self, i):
+        if self.fused:
+            pe.mse_fwd_bwd(self.preds[i % 3], joints=self.j, stride=4.0, sigma=2.0, radius=6,
+                           workspace=self.ws)
+        else:
+            pe.mse_fwd_bwd(self.preds[i % 3], self.t, self.w, workspace=self.ws)
+
+    def cpu_baseline(self):
+        import oracle
+
+        rng = np.random.default_rng(0)
+        p = rng.normal(size=(64, K_JOINTS, H, W)).astype(np.float32)
+        j = synthetic.joints(64, K_JOINTS, 256, 192)
+        t, w = oracle.render_targets(j, H, W, 4.0, 2.0, 6)
+        t0 = time.perf_counter()
+        oracle.mse_fwd_bwd(p, t, w)
+        dt = time.perf_counter() - t0
+        return {"value": 64 / dt, "unit": "images/s", "cores": 1, "kind": "port",
+                "sample": "NumPy oracle, 64-image batch, one run"}
+
+
+class MseFused(Mse):
+    fused = True
+
+
+class Adam(Workload):
+    name = "adam_34M_f32"
+    batch = 1  # one optimizer step
+    kernel = "adam_kernel"
+    n = 34_000_000
+    bytes_per_step = n * 30
+
+    def setup(self, device):
+        self.p = torch.randn(self.n, device=device)
+        self.m = torch.zeros(self.n, device=device)
+        self.v = torch.zeros(self.n, device=device)
+        self.g = torch.randn(self.n, device=device)
+        self.pb = torch.empty(self.n, dtype=torch.bfloat16, device=device)
+
+    def step(self, i):
+        pe.adam_step(self.p, self.m, self.v, self.g, i + 1, p_bf16=self.pb)
+
+    def cpu_baseline(self):
+        import oracle
+
+        n = 4_000_000
+        z = np.zeros(n, np.float32)
+        g = np.ones(n, np.float32)
+        t0 = time.perf_counter()
+        oracle.adam_step(z, z, z, g, 1e-3, 0.9, 0.999, 1e-8, 1)
+        dt = time.perf_counter() - t0
+        return {"value": (n / self.n) / dt, "unit": "steps/s", "cores": 1, "kind": "port",
+                "sample": "NumPy oracle, 4M-parameter slice, scaled to 34M"}
+
+
+WORKLOADS = {"decode": Decode, "render": Render, "mse": Mse, "mse_fused": MseFused, "adam": Adam}
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="decode", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (there is no CPU fallback for the measured path)")
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=device)
+
+    wl = WORKLOADS[args.workload]()
+    wl.setup(device)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    for i in range(args.warmup):
+        wl.step(i)
+    barrier()
+    ev0 = torch.cuda.Event(enable_timing=True)
+    ev1 = torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for i in range(args.steps):
+        wl.step(i)
+    ev1.record()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    dev_ms = ev0.elapsed_time(ev1)  # same stream as the launches (torch's current stream)
+
+    if dist is not None:
+        t = torch.tensor([elapsed, dev_ms], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed, dev_ms = float(t[0]), float(t[1])
+
+    if rank == 0:
+        ms_per_step = elapsed * 1e3 / args.steps
+        kern_ms = dev_ms / args.steps
+        achieved = wl.bytes_per_step / (kern_ms * 1e-3) / 1e9
+        out = {
+            "metric": METRIC,
+            "value": world * wl.batch * args.steps / elapsed,
+            "unit": "images/s" if args.workload != "adam" else "steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": wl.dtype,
+            "data": "synthetic",
+            "config": {"workload": wl.name, "batch_per_gpu": wl.batch, "joints": K_JOINTS,
+                       "heatmap": [H, W], "sharding": "batch, no collective"},
+            "roofline": {"bound": wl.bound, "kernel": wl.kernel, "achieved": achieved,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "bytes_per_launch": wl.bytes_per_step, "launch_ms": kern_ms,
+                         "traffic": None},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = wl.cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,156 @@
+/*
+ * pe_api.h — C ABI of libpe_hip.so, the MI355X (gfx950) pose-estimation hot path.
+ *
+ * The reference (preritj/pose_estimation) is Python-only and exposes no FFI;
+ * the files that held these units are named by its project manifest but are
+ * absent from the snapshot.  Each entry point below cites the reference
+ * location whose work it takes over.
+ *
+ * Conventions
+ *   - every function returns 0 (PE_OK) or a negative PE_E_* code; the message
+ *     of the last failure on the calling thread is pe_last_error();
+ *   - all tensor arguments are caller-owned DEVICE pointers unless a parameter
+ *     is documented as host memory; the library allocates nothing;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream);
+ *     every compute call is asynchronous on that stream and never synchronises;
+ *   - sizes are int32 element counts, strides are int64 element strides.
+ */
+#ifndef PE_API_H
+#define PE_API_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PE_OK             0
+#define PE_E_INVALID     (-1)  /* bad argument (null pointer, negative size, misalignment) */
+#define PE_E_HIP         (-2)  /* a HIP runtime call or kernel launch failed */
+#define PE_E_UNSUPPORTED (-3)  /* valid request outside what the kernels cover */
+
+#define PE_DTYPE_F32  0
+#define PE_DTYPE_BF16 1
+
+#define PE_MAX_RADIUS 31       /* largest Gaussian window radius pe_render/pe_mse accept */
+
+typedef void* pe_stream_t;
+
+/* Library ABI version (major*1000 + minor). */
+int32_t pe_version(void);
+
+/* Message of the most recent failure on this thread ("" if none). Never NULL. */
+const char* pe_last_error(void);
+
+/* Number of HIP devices visible to the library, or PE_E_HIP. Host-only query. */
+int32_t pe_device_count(void);
+
+/* ------------------------------------------------------------------------
+ * a1. Heat-map peak decode.
+ * Replaces: the heat-map -> keypoint step of inference.py / utils/ops.py
+ * (PoseEstimation.pyproj:28,37; both absent).  The notebook's nearest call is
+ * heatmaps[:, :, kp].nonzero() at test.ipynb:931.
+ *
+ * hm is a logical [B,K,H,W] float32 tensor addressed as
+ *   hm[b*sB + k*sK + y*sH + x*sW]
+ * so both NCHW (sW = 1) and the reference's NHWC label layout (sK = 1,
+ * test.ipynb:931) are accepted.  Per (b,k):
+ *   idx  = lowest y*W + x attaining the maximum          -> idx  [B,K] int32
+ *   conf = that maximum                                   -> conf [B,K] float32
+ *   (x,y)= (idx % W, idx / W); if refine != 0 and 1 < x < W-1 and 1 < y < H-1
+ *          each coordinate moves 0.25 towards its larger neighbour (none on a
+ *          tie); if conf <= 0 both are 0                  -> xy [B,K,2] float32
+ * Inputs are assumed finite.
+ * ---------------------------------------------------------------------- */
+int32_t pe_decode_f32(const float* hm, int32_t B, int32_t K, int32_t H, int32_t W,
+                      int64_t sB, int64_t sK, int64_t sH, int64_t sW,
+                      int32_t refine, float* xy, float* conf, int32_t* idx,
+                      pe_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * a2. Gaussian target rendering.
+ * Replaces: the label-map rendering inside the tf.data map function of
+ * dataset/pose_data.py / utils/ops.py (PoseEstimation.pyproj:27,37; absent),
+ * whose output is visible at test.ipynb:606-614, 919-922.
+ *
+ * pe_gaussian_table_f32 is HOST-only: table[i] = (float)exp(-(double)i*i /
+ * (2*sigma*sigma)), i = 0..radius, written to host memory `table`
+ * (radius+1 floats).  It is the table the render / fused-loss kernels use.
+ *
+ * pe_render_targets_f32: joints [B,K,3] float32 = (x, y, v) in input pixels.
+ *   mu      = floor(coord / stride + 0.5)       (float32 arithmetic)
+ *   weight  = 0 if !(v > 0), if a coordinate is not finite, or if the
+ *             (2*radius+1)^2 window around mu lies wholly off the map; else 1
+ *   target  = table[|x-mu_x|] * table[|y-mu_y|] inside the window, 0 elsewhere,
+ *             all 0 when weight == 0
+ * target is a logical [B,K,H,W] float32 tensor addressed through
+ * (tB,tK,tH,tW) like hm above; weight is [B,K] float32, contiguous.
+ * ---------------------------------------------------------------------- */
+int32_t pe_gaussian_table_f32(float sigma, int32_t radius, float* table);
+
+int32_t pe_render_targets_f32(const float* joints, int32_t B, int32_t K, int32_t H, int32_t W,
+                              float stride, float sigma, int32_t radius,
+                              float* target, int64_t tB, int64_t tK, int64_t tH, int64_t tW,
+                              float* weight, pe_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * a3. Masked per-joint MSE loss and its gradient.
+ * Replaces: the heat-map loss of model/base_model.py (PoseEstimation.pyproj:30;
+ * absent); the per-pixel ignore mask is the `masks` label of test.ipynb:949.
+ *
+ *   L    = 0.5/(B*K*H*W) * sum_{b,k,y,x} m[b,y,x] * (w[b,k] * (p - t))^2
+ *   grad = w[b,k]^2 * m[b,y,x] * (p - t) / (B*K*H*W)
+ *
+ * pred / grad: contiguous [B,K,H,W], float32 (PE_DTYPE_F32) or bf16
+ *              (PE_DTYPE_BF16); grad may be NULL (loss only).
+ * Exactly one of `target` (contiguous [B,K,H,W] float32) and `joints`
+ * ([B,K,3] float32) is non-NULL.  With `joints` the target is rendered on the
+ * fly exactly as pe_render_targets_f32 would (stride, sigma, radius) and never
+ * touches memory; `weight` is then an OUTPUT ([B,K], may be NULL).  With
+ * `target`, `weight` is an INPUT [B,K] (NULL = all ones).
+ * mask: [B,H,W] uint8, 0 = ignore pixel; NULL = no mask.
+ * loss: 1 float32; per_joint: K float32 with mean(per_joint) == loss (may be NULL).
+ * workspace: device scratch of at least pe_mse_workspace_bytes(B,K) bytes.
+ * The reduction order is fixed, so results are run-to-run bit-stable.
+ * ---------------------------------------------------------------------- */
+size_t pe_mse_workspace_bytes(int32_t B, int32_t K);
+
+int32_t pe_mse_fwd_bwd(const void* pred, int32_t pred_dtype,
+                       const float* target, const float* joints,
+                       float* weight, const uint8_t* mask,
+                       int32_t B, int32_t K, int32_t H, int32_t W,
+                       float stride, float sigma, int32_t radius,
+                       float* loss, float* per_joint, void* grad,
+                       void* workspace, pe_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * a6. Optimizer steps over a flat float32 parameter arena.
+ * Replaces: the optimizer of train.py / model/base_model.py
+ * (PoseEstimation.pyproj:30,34; absent); hyper-parameters at
+ * test.ipynb:1001-1008 (adam, beta1 0.9, beta2 0.999, epsilon 1e-8, lr 1e-3).
+ *
+ * pe_adam_step: for i < n, with g = grad[i]*grad_scale,
+ *   m = beta1*m + (1-beta1)*g;  v = beta2*v + ((1-beta2)*g)*g
+ *   p -= (step_size*m) / (sqrt(v)*denom_scale + eps)
+ * step_size/denom_scale carry the bias correction and are computed by the
+ * caller: TF-1 Adam is (lr*sqrt(1-b2^t)/(1-b1^t), 1); the eps-on-v_hat form is
+ * (lr/(1-b1^t), 1/sqrt(1-b2^t)).  p_bf16 (may be NULL) receives the bf16
+ * working copy of the updated parameters.
+ *
+ * pe_sgd_step: mom = momentum*mom + g; p -= lr*mom.
+ * All pointers must be 16-byte aligned (p_bf16: 8-byte).
+ * ---------------------------------------------------------------------- */
+int32_t pe_adam_step(float* p, float* m, float* v, const float* grad, uint16_t* p_bf16,
+                     int64_t n, float beta1, float beta2, float eps,
+                     float step_size, float denom_scale, float grad_scale,
+                     pe_stream_t stream);
+
+int32_t pe_sgd_step(float* p, float* mom, const float* grad, uint16_t* p_bf16,
+                    int64_t n, float lr, float momentum, float grad_scale,
+                    pe_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PE_API_H */

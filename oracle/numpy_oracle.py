@@ -1,0 +1,242 @@
+"""NumPy restatement of the bandwidth-bound units of the pose hot path.
+
+TEST INFRASTRUCTURE ONLY (see the package docstring): the product never
+imports this file.  PARITY UNPINNED against the reference's implementation,
+because the reference snapshot holds none; the absent homes of these units
+are named by PoseEstimation.pyproj:28,30,34,37 (inference.py,
+model/base_model.py, train.py, utils/ops.py).  What the reference does pin is
+tested in tests/test_reference_fixture.py.
+
+Every function fixes the *order of float32 operations* so that the HIP kernels,
+which follow the same order with FMA contraction disabled, can be compared
+bit for bit wherever the arithmetic is elementwise.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+F32 = np.float32
+
+
+# --------------------------------------------------------------------------
+# bf16 helpers (round-to-nearest-even on the float32 bit pattern; finite data)
+# --------------------------------------------------------------------------
+def f32_to_bf16_bits(x) -> np.ndarray:
+    """float32 -> bf16 bit pattern (uint16), round-to-nearest-even.  NaN stays NaN."""
+    x = np.ascontiguousarray(x, dtype=F32)
+    u = x.view(np.uint32).astype(np.uint64)
+    r = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16).astype(np.uint16)
+    nan = np.isnan(x)
+    if nan.any():
+        r = np.where(nan, ((u >> 16) | 0x40).astype(np.uint16), r)
+    return r
+
+
+def bf16_bits_to_f32(b) -> np.ndarray:
+    b = np.ascontiguousarray(b, dtype=np.uint16)
+    return (b.astype(np.uint32) << 16).view(F32)
+
+
+def bf16_round(x) -> np.ndarray:
+    """float32 value rounded to the nearest bf16, returned as float32."""
+    return bf16_bits_to_f32(f32_to_bf16_bits(x))
+
+
+# --------------------------------------------------------------------------
+# a1  heat-map peak decode
+# --------------------------------------------------------------------------
+def decode_heatmaps(hm, refine: bool = True):
+    """Per (b, k) map: first arg-max, confidence, quarter-pixel refined (x, y).
+
+    hm: logical [B, K, H, W] float32 with any strides (an NHWC array viewed
+    through .transpose(0, 3, 1, 2) is fine).  Finite inputs assumed.
+
+    idx  = lowest flat index y*W + x of the maximum (numpy.argmax semantics)
+    conf = that maximum
+    x, y = idx % W, idx // W; when 1 < x < W-1 and 1 < y < H-1 each coordinate
+           moves 0.25 towards the larger of its two neighbours (no move on a
+           tie); when conf <= 0 both coordinates are reported as 0.
+    The reference would hold this in inference.py / utils/ops.py
+    (PoseEstimation.pyproj:28,37; absent); its notebook only ever calls
+    heatmaps[:, :, kp].nonzero() (test.ipynb:931).
+    """
+    hm = np.asarray(hm, dtype=F32)
+    B, K, H, W = hm.shape
+    flat = np.ascontiguousarray(hm).reshape(B, K, H * W)
+    idx64 = flat.argmax(axis=2)
+    conf = np.take_along_axis(flat, idx64[..., None], axis=2)[..., 0].astype(F32)
+    x = idx64 % W
+    y = idx64 // W
+    xf = x.astype(F32)
+    yf = y.astype(F32)
+    if refine and H >= 4 and W >= 4:
+        inner = (x > 1) & (x < W - 1) & (y > 1) & (y < H - 1)
+        xc = np.clip(x, 1, W - 2)
+        yc = np.clip(y, 1, H - 2)
+        bi = np.arange(B)[:, None]
+        ki = np.arange(K)[None, :]
+        full = np.ascontiguousarray(hm)
+        dx = full[bi, ki, yc, xc + 1] - full[bi, ki, yc, xc - 1]
+        dy = full[bi, ki, yc + 1, xc] - full[bi, ki, yc - 1, xc]
+        xf = xf + np.where(inner, F32(0.25) * np.sign(dx), F32(0)).astype(F32)
+        yf = yf + np.where(inner, F32(0.25) * np.sign(dy), F32(0)).astype(F32)
+    pos = conf > 0
+    xy = np.stack([np.where(pos, xf, F32(0)), np.where(pos, yf, F32(0))], axis=-1).astype(F32)
+    return xy, conf, idx64.astype(np.int32)
+
+
+# --------------------------------------------------------------------------
+# a2  Gaussian target rendering
+# --------------------------------------------------------------------------
+def gaussian_table(sigma: float, radius: int) -> np.ndarray:
+    """g[i] = float32(exp(-i^2 / (2 sigma^2))) for i = 0..radius, exp in float64.
+
+    sigma is first rounded to float32 (it crosses the C ABI as a float).
+    """
+    s = float(F32(sigma))
+    i = np.arange(int(radius) + 1, dtype=np.float64)
+    return np.exp(-(i * i) / (2.0 * s * s)).astype(F32)
+
+
+def joint_centres(joints, stride: float):
+    """mu = floor(coord / stride + 0.5), evaluated in float32."""
+    j = np.asarray(joints, dtype=F32)
+    st = F32(stride)
+    mx = np.floor(j[..., 0] / st + F32(0.5)).astype(F32)
+    my = np.floor(j[..., 1] / st + F32(0.5)).astype(F32)
+    return mx, my
+
+
+def render_targets(joints, H: int, W: int, stride: float, sigma: float, radius: int):
+    """Gaussian heat-map targets and per-joint weights.
+
+    joints [B, K, 3] float32 = (x, y, v) in input pixels.  Returns
+    target [B, K, H, W] float32 and weight [B, K] float32.
+
+    weight = 0 when v == 0 (or v is not > 0), when a coordinate is not finite,
+    or when the (2r+1)^2 window around mu lies wholly off the map; else 1.
+    target = g[|x - mu_x|] * g[|y - mu_y|] (one float32 product) inside the
+    window, 0 elsewhere, and all zeros when weight == 0.
+    With radius = 1 the support is the 3x3 block the reference's label maps
+    show (test.ipynb:606-614).  The reference would hold this in
+    dataset/pose_data.py / utils/ops.py (PoseEstimation.pyproj:27,37; absent).
+    """
+    j = np.asarray(joints, dtype=F32)
+    B, K, _ = j.shape
+    r = int(radius)
+    g = gaussian_table(sigma, r)
+    mx, my = joint_centres(j, stride)
+    finite = np.isfinite(j[..., 0]) & np.isfinite(j[..., 1])
+    with np.errstate(invalid="ignore"):
+        on = (mx - r < W) & (mx + r >= 0) & (my - r < H) & (my + r >= 0)
+        vis = j[..., 2] > 0
+    wgt = (finite & on & vis)
+    target = np.zeros((B, K, H, W), dtype=F32)
+    xs = np.arange(W)
+    ys = np.arange(H)
+    for b in range(B):
+        for k in range(K):
+            if not wgt[b, k]:
+                continue
+            cx = int(mx[b, k])
+            cy = int(my[b, k])
+            ax = np.abs(xs - cx)
+            ay = np.abs(ys - cy)
+            gx = np.where(ax <= r, g[np.minimum(ax, r)], F32(0)).astype(F32)
+            gy = np.where(ay <= r, g[np.minimum(ay, r)], F32(0)).astype(F32)
+            target[b, k] = gy[:, None] * gx[None, :]
+    return target, wgt.astype(F32)
+
+
+# --------------------------------------------------------------------------
+# a3  masked per-joint MSE loss and gradient
+# --------------------------------------------------------------------------
+def mse_fwd_bwd(pred, target, weight, mask=None, pred_is_bf16: bool = False):
+    """L = 0.5/(B K H W) * sum m (w (p - t))^2 and dL/dp.
+
+    pred   [B, K, H, W] float32, or uint16 bf16 bit patterns when pred_is_bf16
+    target [B, K, H, W] float32
+    weight [B, K] float32
+    mask   [B, H, W] uint8 (0 = ignore) or None
+    Returns loss (float32 scalar), per_joint [K] float32 with
+    mean(per_joint) == loss, and grad (float32, or bf16 bits when
+    pred_is_bf16).
+
+    Float32 order: d = p - t; e = w*d; q = e*e (summed in float64 here; the
+    kernels sum in float32 trees, so the loss is compared with a tolerance);
+    c = (w*w)*inv_n with inv_n = float32(1/(B K H W)); grad = c*d where m else 0
+    (elementwise, compared bit for bit).
+    The reference would hold the loss in model/base_model.py
+    (PoseEstimation.pyproj:30; absent); a per-pixel `masks` label exists at
+    test.ipynb:949.
+    """
+    if pred_is_bf16:
+        p = bf16_bits_to_f32(pred)
+    else:
+        p = np.asarray(pred, dtype=F32)
+    t = np.asarray(target, dtype=F32)
+    w = np.asarray(weight, dtype=F32)
+    B, K, H, W = p.shape
+    n = B * K * H * W
+    inv_n = F32(1.0 / n)
+    d = (p - t).astype(F32)
+    e = (w[:, :, None, None] * d).astype(F32)
+    q = (e * e).astype(F32)
+    c = ((w * w).astype(F32) * inv_n).astype(F32)
+    g = (c[:, :, None, None] * d).astype(F32)
+    if mask is not None:
+        m = np.asarray(mask).astype(bool)[:, None, :, :]
+        q = np.where(m, q, F32(0))
+        g = np.where(m, g, F32(0)).astype(F32)
+    sums = q.astype(np.float64).sum(axis=(0, 2, 3))
+    per_joint = (sums * (0.5 / (B * H * W))).astype(F32)
+    loss = F32(sums.sum() * (0.5 / n))
+    grad = f32_to_bf16_bits(g) if pred_is_bf16 else g
+    return loss, per_joint, grad
+
+
+# --------------------------------------------------------------------------
+# a6  optimizer steps over a flat float32 arena
+# --------------------------------------------------------------------------
+def adam_scalars(lr: float, beta1: float, beta2: float, step: int, tf1: bool = True):
+    """Host-side scalars (s, a) for the update p -= s * m / (sqrt(v) * a + eps).
+
+    tf1=True  : s = lr*sqrt(1-b2^t)/(1-b1^t), a = 1   (tf.train.AdamOptimizer,
+                the reference's optimizer by name: test.ipynb:1007-1008)
+    tf1=False : s = lr/(1-b1^t), a = 1/sqrt(1-b2^t)   (eps on sqrt(v_hat))
+    """
+    bc1 = 1.0 - beta1 ** step
+    bc2 = 1.0 - beta2 ** step
+    if tf1:
+        return F32(lr * np.sqrt(bc2) / bc1), F32(1.0)
+    return F32(lr / bc1), F32(1.0 / np.sqrt(bc2))
+
+
+def adam_step(p, m, v, g, lr, beta1, beta2, eps, step, tf1=True, grad_scale=1.0):
+    """One Adam step, float32 elementwise in a fixed order.  Returns new
+    (p, m, v, p_bf16_bits)."""
+    p = np.asarray(p, dtype=F32)
+    m = np.asarray(m, dtype=F32)
+    v = np.asarray(v, dtype=F32)
+    g = (np.asarray(g, dtype=F32) * F32(grad_scale)).astype(F32)
+    b1 = F32(beta1)
+    b2 = F32(beta2)
+    omb1 = F32(1.0 - float(b1))  # formed from the float32 betas, as the C ABI receives them
+    omb2 = F32(1.0 - float(b2))
+    s, a = adam_scalars(lr, beta1, beta2, step, tf1)
+    m2 = ((b1 * m).astype(F32) + (omb1 * g).astype(F32)).astype(F32)
+    v2 = ((b2 * v).astype(F32) + ((omb2 * g).astype(F32) * g).astype(F32)).astype(F32)
+    den = ((np.sqrt(v2).astype(F32) * a).astype(F32) + F32(eps)).astype(F32)
+    upd = ((s * m2).astype(F32) / den).astype(F32)
+    p2 = (p - upd).astype(F32)
+    return p2, m2, v2, f32_to_bf16_bits(p2)
+
+
+def sgd_step(p, mom, g, lr, momentum, grad_scale=1.0):
+    """Momentum SGD: mom = momentum*mom + g; p -= lr*mom (float32, fixed order)."""
+    p = np.asarray(p, dtype=F32)
+    mom = np.asarray(mom, dtype=F32)
+    g = (np.asarray(g, dtype=F32) * F32(grad_scale)).astype(F32)
+    mom2 = ((F32(momentum) * mom).astype(F32) + g).astype(F32)
+    p2 = (p - (F32(lr) * mom2).astype(F32)).astype(F32)
+    return p2, mom2, f32_to_bf16_bits(p2)

@@ -1,0 +1,89 @@
+"""ctypes binding of libpe_hip.so (the C ABI declared in include/pe_api.h).
+
+There is no CPU fallback: if the shared library is missing, loading fails with
+an instruction to build it, and every op raises if its tensors are not on a GPU.
+"""
+from __future__ import annotations
+
+import ctypes
+from ctypes import c_char_p, c_float, c_int32, c_int64, c_size_t, c_void_p
+from pathlib import Path
+
+LIB_PATH = Path(__file__).resolve().parent / "lib" / "libpe_hip.so"
+
+PE_OK = 0
+PE_E_INVALID = -1
+PE_E_HIP = -2
+PE_E_UNSUPPORTED = -3
+PE_DTYPE_F32 = 0
+PE_DTYPE_BF16 = 1
+PE_MAX_RADIUS = 31
+
+
+class PeError(RuntimeError):
+    """A libpe_hip.so entry point returned a negative status."""
+
+    def __init__(self, code: int, message: str):
+        super().__init__(f"libpe_hip status {code}: {message}")
+        self.code = code
+        self.message = message
+
+
+# name -> (restype, argtypes); must list every symbol include/pe_api.h declares.
+SIGNATURES = {
+    "pe_version": (c_int32, []),
+    "pe_last_error": (c_char_p, []),
+    "pe_device_count": (c_int32, []),
+    "pe_decode_f32": (
+        c_int32,
+        [c_void_p, c_int32, c_int32, c_int32, c_int32, c_int64, c_int64, c_int64, c_int64,
+         c_int32, c_void_p, c_void_p, c_void_p, c_void_p],
+    ),
+    "pe_gaussian_table_f32": (c_int32, [c_float, c_int32, c_void_p]),
+    "pe_render_targets_f32": (
+        c_int32,
+        [c_void_p, c_int32, c_int32, c_int32, c_int32, c_float, c_float, c_int32,
+         c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p],
+    ),
+    "pe_mse_workspace_bytes": (c_size_t, [c_int32, c_int32]),
+    "pe_mse_fwd_bwd": (
+        c_int32,
+        [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p,
+         c_int32, c_int32, c_int32, c_int32, c_float, c_float, c_int32,
+         c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
+    ),
+    "pe_adam_step": (
+        c_int32,
+        [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
+         c_float, c_float, c_float, c_float, c_float, c_float, c_void_p],
+    ),
+    "pe_sgd_step": (
+        c_int32,
+        [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_void_p],
+    ),
+}
+
+_lib = None
+
+
+def lib() -> ctypes.CDLL:
+    """The loaded library; raises loudly if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not LIB_PATH.exists():
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: the HIP extension has not been built. "
+                "Run `python -m pose_estimation_amd.build` (needs hipcc); there is no CPU fallback."
+            )
+        handle = ctypes.CDLL(str(LIB_PATH))
+        for name, (restype, argtypes) in SIGNATURES.items():
+            fn = getattr(handle, name)  # AttributeError if the .so is stale
+            fn.restype = restype
+            fn.argtypes = argtypes
+        _lib = handle
+    return _lib
+
+
+def check(status: int) -> None:
+    if status != PE_OK:
+        raise PeError(status, lib().pe_last_error().decode("utf-8", "replace"))

@@ -1,0 +1,84 @@
+// Internal helpers shared by the HIP translation units of libpe_hip.so (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "pe_api.h"
+
+namespace pe {
+
+// Records the message returned by pe_last_error() on this thread.
+void set_error(const char* fmt, ...) __attribute__((format(printf, 1, 2)));
+void clear_error();
+
+constexpr int kWave = 64;  // gfx950 wavefront width
+
+struct GaussTable {
+    float g[PE_MAX_RADIUS + 1];
+};
+
+// Fills t.g[0..radius] exactly as pe_gaussian_table_f32 does; entries past radius are 0.
+void fill_gauss_table(float sigma, int radius, GaussTable* t);
+
+inline hipStream_t as_stream(pe_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+// Checks the launch that was just enqueued; returns PE_OK or PE_E_HIP.
+int32_t check_launch(const char* what);
+
+inline bool aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
+
+}  // namespace pe
+
+#define PE_REQUIRE(cond, code, ...)          \
+    do {                                     \
+        if (!(cond)) {                       \
+            pe::set_error(__VA_ARGS__);      \
+            return (code);                   \
+        }                                    \
+    } while (0)
+
+#ifdef __HIPCC__
+namespace pe {
+
+// Native 16-byte vector types: the non-temporal load/store builtins accept only these.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+// (value, index) arg-max combine with numpy.argmax tie-breaking: the larger value wins and,
+// between equal values, the lower index.
+__device__ __forceinline__ void argmax_combine(float& v, int& i, float ov, int oi) {
+    const bool take = (ov > v) || (ov == v && oi < i);
+    v = take ? ov : v;
+    i = take ? oi : i;
+}
+
+__device__ __forceinline__ void wave_argmax(float& v, int& i) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const float ov = __shfl_xor(v, off, 64);
+        const int oi = __shfl_xor(i, off, 64);
+        argmax_combine(v, i, ov, oi);
+    }
+}
+
+// Butterfly sum: every lane ends with the same value, and the order of additions is fixed.
+__device__ __forceinline__ float wave_sum(float x) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) x += __shfl_xor(x, off, 64);
+    return x;
+}
+
+__device__ __forceinline__ float bf16_bits_to_float(uint32_t b) { return __uint_as_float(b << 16); }
+
+// Round-to-nearest-even float -> bf16 bits for finite inputs (NaN keeps a quiet-NaN pattern).
+__device__ __forceinline__ uint32_t float_to_bf16_bits(float f) {
+    const uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+
+}  // namespace pe
+#endif
