@@ -233,7 +233,7 @@ def test_adam_tf1_form_first_step_is_lr_sized():
     g = np.array([0.5, -2.0, 1e-3], F32)
     p, m, v, _ = oracle.adam_step(np.zeros(3, F32), np.zeros(3, F32), np.zeros(3, F32), g,
                                   1e-3, 0.9, 0.999, 1e-8, 1, tf1=True)
-    assert np.allclose(p, -1e-3 * np.sign(g), rtol=1e-4)
+    assert np.allclose(p, -1e-3 * np.sign(g), rtol=1e-3)  # eps is 3e-4 of sqrt(v) at g = 1e-3
     assert np.allclose(m, 0.1 * g, rtol=1e-6) and np.allclose(v, 1e-3 * g * g, rtol=1e-5)
 
 
