@@ -234,7 +234,7 @@ def test_adam_tf1_form_first_step_is_lr_sized():
     p, m, v, _ = oracle.adam_step(np.zeros(3, F32), np.zeros(3, F32), np.zeros(3, F32), g,
                                   1e-3, 0.9, 0.999, 1e-8, 1, tf1=True)
     assert np.allclose(p, -1e-3 * np.sign(g), rtol=1e-3)  # eps is 3e-4 of sqrt(v) at g = 1e-3
-    assert np.allclose(m, 0.1 * g, rtol=1e-6) and np.allclose(v, 1e-3 * g * g, rtol=1e-5)
+    assert np.allclose(m, 0.1 * g, rtol=1e-6) and np.allclose(v, 1e-3 * g * g, rtol=1e-4)  # 1 - float32(0.999) is 1.3e-5 off 1e-3
 
 
 def test_sgd_momentum_tracks_torch_sgd():
