@@ -266,6 +266,13 @@ def main() -> None:
                          "bytes_per_launch": wl.bytes_per_step, "launch_ms": kern_ms,
                          "traffic": None},
         }
+        # HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE,
+        # gfx950-corrected); null when this workload has not been profiled.
+        tfile = ROOT / "profiles" / "traffic.json"
+        if tfile.exists():
+            rec = json.loads(tfile.read_text()).get(wl.name)
+            if rec:
+                out["roofline"]["traffic"] = rec["traffic_bytes_per_launch"]
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = wl.cpu_baseline()
         print(json.dumps(out), flush=True)
