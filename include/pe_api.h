@@ -150,6 +150,56 @@ int32_t pe_sgd_step(float* p, float* mom, const float* grad, uint16_t* p_bf16,
                     int64_t n, float lr, float momentum, float grad_scale,
                     pe_stream_t stream);
 
+/* ------------------------------------------------------------------------
+ * a4 / a5. Convolution backbone and deconvolution head (bf16 MFMA implicit GEMM).
+ * Replaces: nets/mobilenet_v2.py, model/mobilenet_pose.py, model/base_model.py
+ * (PoseEstimation.pyproj:30-32; absent) - the conv / deconv arithmetic the
+ * reference delegated to TensorFlow 1.x kernels.
+ *
+ * Tensors: activations are NHWC bf16; packed weights are bf16 with the
+ * reduction axis contiguous:
+ *   conv    : [Cout][KH][KW][Cin]
+ *   deconv  : [4 phases][Cout][2x2 taps][Cin]   (phase = 2*py + px of the output
+ *             pixel parity; tap (a, b) of phase (py, px) is kernel element
+ *             kh = (py ? 2 - 2a : 1 + 2a) ... see pe_pack layout in ops.py)
+ * Accumulation is fp32.  Epilogue: y = acc*scale[c] + shift[c] (+ residual)
+ * (-> ReLU) -> bf16; scale/shift/residual may be NULL.
+ * Cin must be a multiple of 64, Cout a multiple of 4 (except f32-NCHW output).
+ * ---------------------------------------------------------------------- */
+typedef struct pe_conv_desc {
+    int32_t B, H, W, Cin;       /* input  [B,H,W,Cin] */
+    int32_t Cout, KH, KW;       /* filter */
+    int32_t stride, pad;
+    int32_t relu;               /* 1: ReLU in the epilogue */
+    int32_t out_f32_nchw;       /* 0: y is bf16 NHWC [B,Ho,Wo,Cout]; 1: float32 NCHW [B,Cout,Ho,Wo] */
+} pe_conv_desc;
+
+int32_t pe_conv2d_fwd_bf16(const pe_conv_desc* d, const void* x, const void* w,
+                           const float* scale, const float* shift, const void* residual,
+                           void* y, pe_stream_t stream);
+
+/* ConvTranspose 4x4, stride 2, pad 1: x [B,H,W,Cin] -> y [B,2H,2W,Cout], four parity phases. */
+int32_t pe_deconv4x4s2_fwd_bf16(int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout,
+                                int32_t relu, const void* x, const void* w_phases,
+                                const float* scale, const float* shift, void* y,
+                                pe_stream_t stream);
+
+/* 7x7 stride-2 pad-3 stem on a 3-channel image, computed as a 4x4 stride-1 conv over the
+ * 2x2 space-to-depth image: x_s2d [B,H/2,W/2,16] bf16 (12 real channels (ry,rx,c) + 4 zero),
+ * w [Cout][4 rows][4 cols x 16] bf16 -> y [B,H/2,W/2,Cout]. */
+int32_t pe_stem7x7s2_fwd_bf16(int32_t B, int32_t H2, int32_t W2, int32_t Cout, int32_t relu,
+                              const void* x_s2d, const void* w, const float* scale,
+                              const float* shift, void* y, pe_stream_t stream);
+
+/* uint8 RGB [B,H,W,3] -> (x/255 - mean[c]) / std[c] -> bf16 space-to-depth [B,H/2,W/2,16]. */
+int32_t pe_preprocess_u8_s2d_bf16(const uint8_t* img, int32_t B, int32_t H, int32_t W,
+                                  const float* mean3, const float* std3, void* x_s2d,
+                                  pe_stream_t stream);
+
+/* 3x3 stride-2 pad-1 max pool, NHWC bf16: [B,H,W,C] -> [B,H/2,W/2,C] (H, W even; C % 8 == 0). */
+int32_t pe_maxpool3x3s2_fwd_bf16(const void* x, int32_t B, int32_t H, int32_t W, int32_t C,
+                                 void* y, pe_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

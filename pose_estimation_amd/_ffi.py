@@ -61,7 +61,35 @@ SIGNATURES = {
         c_int32,
         [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_float, c_void_p],
     ),
+    "pe_conv2d_fwd_bf16": (
+        c_int32,
+        [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
+    ),
+    "pe_deconv4x4s2_fwd_bf16": (
+        c_int32,
+        [c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p,
+         c_void_p, c_void_p, c_void_p],
+    ),
+    "pe_stem7x7s2_fwd_bf16": (
+        c_int32,
+        [c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p,
+         c_void_p, c_void_p],
+    ),
+    "pe_preprocess_u8_s2d_bf16": (
+        c_int32,
+        [c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p],
+    ),
+    "pe_maxpool3x3s2_fwd_bf16": (
+        c_int32, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p],
+    ),
 }
+
+
+class ConvDesc(ctypes.Structure):
+    """Mirror of pe_conv_desc (include/pe_api.h)."""
+
+    _fields_ = [(n, c_int32) for n in ("B", "H", "W", "Cin", "Cout", "KH", "KW", "stride", "pad",
+                                       "relu", "out_f32_nchw")]
 
 _lib = None
 

@@ -1,0 +1,46 @@
+// Implicit-GEMM convolution engine for gfx950 (bf16 MFMA, fp32 accumulate).
+//
+// One kernel family serves every dense convolution on the path:
+//   forward conv (1x1 / 3x3 / 7x7-as-space-to-depth, stride 1 or 2), the four output-parity
+//   phases of the stride-2 transposed conv, and every backward-data pass (a backward-data pass
+//   is itself a gather-conv over the output gradient with re-packed weights).
+//
+//   D[n][m] = sum_{tap, c} Wp[n][tap*Cin + c] * X[b, oy*sy + dy(tap), ox*sx + dx(tap), c]
+//
+//   m enumerates GEMM rows (b, oy, ox) over a Ho x Wo grid; the result lands at output pixel
+//   (b, oy*osy + ooy, ox*osx + oox) of an OH x OW map, which is how a deconv phase scatters.
+#pragma once
+
+#include "pe_common.h"
+
+namespace pe {
+
+constexpr int kMaxTaps = 64;
+
+struct IgemmParams {
+    const uint16_t* x;      // activations, NHWC bf16, Cx channels per pixel
+    const uint16_t* w;      // packed weights [N][T*Cin] bf16, K contiguous
+    void* y;                // output
+    const float* scale;     // per-output-channel scale (null = 1)
+    const float* shift;     // per-output-channel shift / bias (null = 0)
+    const uint16_t* res;    // residual added before ReLU, laid out like a bf16 NHWC y (null = none)
+    int B, Hi, Wi, Cx;      // input geometry
+    int Ho, Wo;             // GEMM row grid
+    int sy, sx;             // input step per GEMM row step
+    int N;                  // output channels
+    int Cin;                // K elements per tap, multiple of 64 (may span pixels: see cshift)
+    int cshift;             // log2(Cx) when a tap's K run spans several pixels, else 31
+    int cmask;              // Cx-1 in that case, else 0x7fffffff
+    int T;                  // taps
+    int OH, OW, osy, osx, ooy, oox;  // output scatter
+    int ldc;                // output channels per pixel (bf16 NHWC) / unused for f32 NCHW
+    int relu;
+    int out_mode;           // 0: bf16 NHWC   1: f32 NCHW [B][N][OH*OW]
+    int16_t tap_dy[kMaxTaps];
+    int16_t tap_dx[kMaxTaps];
+};
+
+// Launches the engine (asynchronous).  Returns PE_OK / PE_E_*.
+int32_t igemm_launch(const IgemmParams& p, hipStream_t st, const char* what);
+
+}  // namespace pe

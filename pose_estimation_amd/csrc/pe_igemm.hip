@@ -1,0 +1,273 @@
+// Implicit-GEMM convolution kernel: bf16 MFMA 16x16x32, fp32 accumulate, LDS-staged tiles.
+//
+// Workgroup = 256 threads = 4 waves (2 along m x 2 along n), output tile 128 (pixels) x BN
+// (channels), K step 64.  Activations and weights are staged global -> registers -> LDS with the
+// next K step's global loads in flight while the current one is multiplied (two LDS buffers,
+// one barrier per K step).  LDS rows are 64 + 16 bf16 (160 B): with that pitch the 16-lane groups
+// of ds_read_b128 touch 16 distinct 16-byte bank slots, so fragment reads are conflict-free.
+//
+// The MFMA "A" operand is the weight tile and the "B" operand the activation tile, so a lane's
+// four accumulator registers are four consecutive output channels of one pixel: the epilogue
+// (scale, shift, residual, ReLU, bf16 convert) stores 8 contiguous bytes per tile in NHWC.
+#include "pe_igemm.h"
+
+namespace pe {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int BM = 128;
+constexpr int BK = 64;
+constexpr int LDS_ROW = 80;  // bf16 elements per LDS row
+
+__device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {
+    return float_to_bf16_bits(a) | (float_to_bf16_bits(b) << 16);
+}
+
+template <int BN>
+__global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int TM = 4;            // 16-pixel tiles per wave (wave covers 64 pixels)
+    constexpr int TN = BN / 32;      // 16-channel tiles per wave (wave covers BN/2 channels)
+    constexpr int WROWS = BN / 32;   // weight rows staged per thread
+    constexpr int BUF = (BM + BN) * LDS_ROW;
+    uint16_t* lds = reinterpret_cast<uint16_t*>(smem);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = tid >> 6;
+    const int wave_m = wid >> 1;
+    const int wave_n = wid & 1;
+
+    const long M = (long)p.B * p.Ho * p.Wo;
+    const int ntn = (p.N + BN - 1) / BN;
+
+    // XCD-aware tile order: workgroups that share an XCD (ids congruent mod 8) take a
+    // contiguous run of tiles, so the n-tiles of one pixel panel reuse that XCD's L2.
+    int bid = blockIdx.x;
+    {
+        const int nwg = gridDim.x;
+        const int q = nwg >> 3, r = nwg & 7;
+        const int xcd = bid & 7, loc = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    }
+    const int tile_m = bid / ntn;
+    const int tile_n = bid - tile_m * ntn;
+    const long m0 = (long)tile_m * BM;
+    const int n0 = tile_n * BN;
+
+    // ---- staging assignment: thread owns 16-byte chunk `cc` of rows r0 + 32*i
+    const int cc = tid & 7;
+    const int r0 = tid >> 3;
+    const int HoWo = p.Ho * p.Wo;
+    int iy0[4], ix0[4], pixbase[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const long m = m0 + r0 + 32 * i;
+        if (m < M) {
+            const int b = (int)(m / HoWo);
+            const int rem = (int)(m - (long)b * HoWo);
+            const int oy = rem / p.Wo;
+            const int ox = rem - oy * p.Wo;
+            iy0[i] = oy * p.sy;
+            ix0[i] = ox * p.sx;
+            pixbase[i] = b * p.Hi * p.Wi;
+        } else {
+            iy0[i] = -(1 << 20);  // never in range
+            ix0[i] = 0;
+            pixbase[i] = 0;
+        }
+    }
+    const int kc = p.Cin / BK;          // K steps per tap
+    const int KT = p.T * kc;            // K steps in total
+    const long ktot = (long)p.T * p.Cin;  // weight row length
+
+    uint4 xr[4], wr[WROWS];
+    int tap = 0, cstep = 0;  // position of the NEXT tile to load
+
+    auto load_tile = [&](int kt) {
+        const int dy = p.tap_dy[tap];
+        const int dx = p.tap_dx[tap];
+        const int coff = cstep * BK + cc * 8;
+        const int xextra = coff >> p.cshift;
+        const int ch = coff & p.cmask;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int iy = iy0[i] + dy;
+            const int ix = ix0[i] + dx + xextra;
+            const bool ok = (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+            const long off = (long)(pixbase[i] + iy * p.Wi + ix) * p.Cx + ch;
+            xr[i] = ok ? *reinterpret_cast<const uint4*>(p.x + off) : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < WROWS; ++i) {
+            const int n = n0 + r0 + 32 * i;
+            const long off = (long)n * ktot + (long)kt * BK + cc * 8;
+            wr[i] = (n < p.N) ? *reinterpret_cast<const uint4*>(p.w + off) : make_uint4(0, 0, 0, 0);
+        }
+        if (++cstep == kc) {
+            cstep = 0;
+            ++tap;
+        }
+    };
+    auto store_tile = [&](int buf) {
+        uint16_t* xs = lds + buf * BUF;
+        uint16_t* ws = xs + BM * LDS_ROW;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            *reinterpret_cast<uint4*>(xs + (r0 + 32 * i) * LDS_ROW + cc * 8) = xr[i];
+#pragma unroll
+        for (int i = 0; i < WROWS; ++i)
+            *reinterpret_cast<uint4*>(ws + (r0 + 32 * i) * LDS_ROW + cc * 8) = wr[i];
+    };
+
+    f32x4 acc[TN][TM];
+#pragma unroll
+    for (int a = 0; a < TN; ++a)
+#pragma unroll
+        for (int b = 0; b < TM; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int lr = lane & 15;
+    const int lk = (lane >> 4) * 8;
+
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    for (int kt = 0; kt < KT; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < KT) load_tile(kt + 1);
+        const uint16_t* xs = lds + buf * BUF + (wave_m * 64) * LDS_ROW;
+        const uint16_t* ws = lds + buf * BUF + BM * LDS_ROW + (wave_n * (BN / 2)) * LDS_ROW;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 af[TN], bfr[TM];
+#pragma unroll
+            for (int a = 0; a < TN; ++a)
+                af[a] = *reinterpret_cast<const bf16x8*>(ws + (a * 16 + lr) * LDS_ROW + kk * 32 + lk);
+#pragma unroll
+            for (int b = 0; b < TM; ++b)
+                bfr[b] = *reinterpret_cast<const bf16x8*>(xs + (b * 16 + lr) * LDS_ROW + kk * 32 + lk);
+#pragma unroll
+            for (int a = 0; a < TN; ++a)
+#pragma unroll
+                for (int b = 0; b < TM; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bfr[b], acc[a][b], 0, 0, 0);
+        }
+        if (kt + 1 < KT) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue
+    const bool identity = (p.osy == 1 && p.osx == 1 && p.ooy == 0 && p.oox == 0 &&
+                           p.OH == p.Ho && p.OW == p.Wo);
+    const int OHW = p.OH * p.OW;
+    const int nq = (lane >> 4) * 4;
+#pragma unroll
+    for (int b = 0; b < TM; ++b) {
+        const long m = m0 + wave_m * 64 + b * 16 + lr;
+        if (m >= M) continue;
+        long opix;
+        int ob = 0, opl = 0;  // image index and pixel within the image (f32 NCHW mode)
+        if (identity && p.out_mode == 0) {
+            opix = m;
+        } else {
+            const int bb = (int)(m / HoWo);
+            const int rem = (int)(m - (long)bb * HoWo);
+            const int oy = rem / p.Wo;
+            const int ox = rem - oy * p.Wo;
+            opl = (oy * p.osy + p.ooy) * p.OW + ox * p.osx + p.oox;
+            ob = bb;
+            opix = (long)bb * OHW + opl;
+        }
+#pragma unroll
+        for (int a = 0; a < TN; ++a) {
+            const int n = n0 + wave_n * (BN / 2) + a * 16 + nq;
+            if (n >= p.N) continue;
+            float v[4] = {acc[a][b].x, acc[a][b].y, acc[a][b].z, acc[a][b].w};
+            const bool full = (n + 3 < p.N);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (full || n + j < p.N) {
+                    const float sc = p.scale ? p.scale[n + j] : 1.0f;
+                    const float sh = p.shift ? p.shift[n + j] : 0.0f;
+                    v[j] = v[j] * sc + sh;
+                }
+            }
+            if (p.out_mode == 0) {
+                uint16_t* dst = reinterpret_cast<uint16_t*>(p.y) + opix * p.ldc + n;
+                if (full) {
+                    if (p.res) {
+                        const uint2 rv = *reinterpret_cast<const uint2*>(p.res + opix * p.ldc + n);
+                        v[0] += bf16_bits_to_float(rv.x & 0xffffu);
+                        v[1] += bf16_bits_to_float(rv.x >> 16);
+                        v[2] += bf16_bits_to_float(rv.y & 0xffffu);
+                        v[3] += bf16_bits_to_float(rv.y >> 16);
+                    }
+                    if (p.relu) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.0f);
+                    }
+                    uint2 o;
+                    o.x = pack_bf16x2(v[0], v[1]);
+                    o.y = pack_bf16x2(v[2], v[3]);
+                    *reinterpret_cast<uint2*>(dst) = o;
+                } else {
+                    for (int j = 0; j < 4 && n + j < p.N; ++j) {
+                        float t = v[j];
+                        if (p.res) t += bf16_bits_to_float(p.res[opix * p.ldc + n + j]);
+                        if (p.relu) t = fmaxf(t, 0.0f);
+                        dst[j] = (uint16_t)float_to_bf16_bits(t);
+                    }
+                }
+            } else {
+                float* y32 = reinterpret_cast<float*>(p.y);
+                for (int j = 0; j < 4 && n + j < p.N; ++j) {
+                    float t = v[j];
+                    if (p.relu) t = fmaxf(t, 0.0f);
+                    y32[((long)ob * p.N + n + j) * OHW + opl] = t;
+                }
+            }
+        }
+    }
+}
+
+int32_t igemm_launch(const IgemmParams& p, hipStream_t st, const char* what) {
+    PE_REQUIRE(p.x && p.w && p.y, PE_E_INVALID, "%s: NULL tensor pointer", what);
+    PE_REQUIRE(p.B > 0 && p.Hi > 0 && p.Wi > 0 && p.Ho > 0 && p.Wo > 0 && p.N > 0, PE_E_INVALID,
+               "%s: sizes must be positive", what);
+    PE_REQUIRE(p.Cin > 0 && p.Cin % BK == 0, PE_E_UNSUPPORTED,
+               "%s: K per tap (%d) must be a multiple of %d", what, p.Cin, BK);
+    PE_REQUIRE(p.Cx % 8 == 0, PE_E_UNSUPPORTED, "%s: channels per pixel (%d) must be a multiple of 8",
+               what, p.Cx);
+    PE_REQUIRE(p.T >= 1 && p.T <= kMaxTaps, PE_E_UNSUPPORTED, "%s: %d taps (max %d)", what, p.T,
+               kMaxTaps);
+    PE_REQUIRE(aligned(p.x, 16) && aligned(p.w, 16) && aligned(p.y, 8) && aligned(p.res, 8),
+               PE_E_INVALID, "%s: tensors must be 16-byte aligned", what);
+    PE_REQUIRE(p.out_mode == 1 || p.ldc % 4 == 0, PE_E_UNSUPPORTED,
+               "%s: output channel pitch must be a multiple of 4", what);
+    const long M = (long)p.B * p.Ho * p.Wo;
+    PE_REQUIRE((long)p.B * p.Hi * p.Wi < 0x7fffffffL && M < 0x7fffffffL &&
+                   (long)p.B * p.OH * p.OW < 0x7fffffffL,
+               PE_E_UNSUPPORTED, "%s: pixel count does not fit int32", what);
+    const long ntm = (M + BM - 1) / BM;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_kernel<128>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  2 * (BM + 128) * LDS_ROW * 2);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_kernel<64>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  2 * (BM + 64) * LDS_ROW * 2);
+        attr_set = true;
+    }
+    if (p.N > 64) {
+        const long ntn = (p.N + 127) / 128;
+        const size_t lds = 2 * (BM + 128) * LDS_ROW * sizeof(uint16_t);
+        igemm_kernel<128><<<(unsigned)(ntm * ntn), 256, lds, st>>>(p);
+    } else {
+        const size_t lds = 2 * (BM + 64) * LDS_ROW * sizeof(uint16_t);
+        igemm_kernel<64><<<(unsigned)ntm, 256, lds, st>>>(p);
+    }
+    return check_launch(what);
+}
+
+}  // namespace pe

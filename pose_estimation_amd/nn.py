@@ -1,0 +1,168 @@
+"""Layer-level wrappers over the conv / deconv C ABI plus the weight packers.
+
+Activations are NHWC bfloat16 torch tensors (buffers only); packed weights are bfloat16 with
+the reduction axis contiguous.  The packers take weights in the usual framework layouts
+(conv: [Cout,Cin,KH,KW]; transposed conv: [Cin,Cout,KH,KW]) so a checkpoint of the reference
+architecture can be loaded tensor by tensor.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional
+
+import torch
+
+from ._ffi import ConvDesc, check, lib
+from .ops import _need_gpu, _ptr, _stream
+
+BF16 = torch.bfloat16
+
+
+# --------------------------------------------------------------------------- packers
+def pack_conv_weight(w_oihw: torch.Tensor) -> torch.Tensor:
+    """[Cout,Cin,KH,KW] -> bf16 [Cout,KH,KW,Cin]."""
+    return w_oihw.permute(0, 2, 3, 1).contiguous().to(BF16)
+
+
+def deconv_phase_taps(py: int, a: int):
+    """Kernel index and input offset of tap `a` (0/1) of output parity `py` for a 4x4,
+    stride-2, pad-1 transposed conv: out[2Y+py] += in[Y+d] * w[k]."""
+    if py == 0:
+        return (1, 0) if a == 0 else (3, -1)
+    return (2, 0) if a == 0 else (0, 1)
+
+
+def pack_deconv_weight(w_iohw: torch.Tensor) -> torch.Tensor:
+    """ConvTranspose2d weight [Cin,Cout,4,4] -> bf16 [4 phases, Cout, 4 taps, Cin]
+    (phase = 2*py+px, tap = 2*a+b)."""
+    cin, cout, kh, kw = w_iohw.shape
+    assert kh == 4 and kw == 4
+    out = torch.empty(4, cout, 4, cin, dtype=w_iohw.dtype, device=w_iohw.device)
+    for py in range(2):
+        for px in range(2):
+            for a in range(2):
+                for b in range(2):
+                    k_y, _ = deconv_phase_taps(py, a)
+                    k_x, _ = deconv_phase_taps(px, b)
+                    out[2 * py + px, :, 2 * a + b, :] = w_iohw[:, :, k_y, k_x].t()
+    return out.contiguous().to(BF16)
+
+
+def pack_stem_weight(w_oihw: torch.Tensor) -> torch.Tensor:
+    """7x7 stride-2 pad-3 stem weight [Cout,3,7,7] -> bf16 [Cout, 4 rows, 4 cols * 16] for the
+    equivalent 4x4 stride-1 conv over the 2x2 space-to-depth image (channel = (ry*2+rx)*3+c)."""
+    cout = w_oihw.shape[0]
+    assert tuple(w_oihw.shape[1:]) == (3, 7, 7)
+    out = torch.zeros(cout, 4, 4, 16, dtype=w_oihw.dtype, device=w_oihw.device)
+    for dY in range(-2, 2):
+        for ry in range(2):
+            kh = 2 * dY + ry + 3
+            if not 0 <= kh < 7:
+                continue
+            for dX in range(-2, 2):
+                for rx in range(2):
+                    kw = 2 * dX + rx + 3
+                    if not 0 <= kw < 7:
+                        continue
+                    s = (ry * 2 + rx) * 3
+                    out[:, dY + 2, dX + 2, s:s + 3] = w_oihw[:, :, kh, kw]
+    return out.reshape(cout, 4, 64).contiguous().to(BF16)
+
+
+# --------------------------------------------------------------------------- layers
+def _check_act(x: torch.Tensor, name: str = "x"):
+    _need_gpu(x)
+    if x.dtype != BF16 or x.dim() != 4 or not x.is_contiguous():
+        raise ValueError(f"{name} must be a contiguous NHWC bfloat16 tensor")
+
+
+def conv2d(x: torch.Tensor, w: torch.Tensor, scale: Optional[torch.Tensor] = None,
+           shift: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
+           stride: int = 1, pad: int = 0, relu: bool = False, out_f32_nchw: bool = False,
+           out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """y = relu?( conv(x, w) * scale + shift + residual ).  x [B,H,W,Cin], w [Cout,KH,KW,Cin]."""
+    _check_act(x)
+    _need_gpu(w, scale, shift, residual, out)
+    B, H, W, Cin = x.shape
+    Cout, KH, KW, Cin2 = w.shape
+    if Cin2 != Cin or w.dtype != BF16 or not w.is_contiguous():
+        raise ValueError("w must be contiguous bfloat16 [Cout,KH,KW,Cin]")
+    Ho = (H + 2 * pad - KH) // stride + 1
+    Wo = (W + 2 * pad - KW) // stride + 1
+    if out is None:
+        if out_f32_nchw:
+            out = torch.empty((B, Cout, Ho, Wo), dtype=torch.float32, device=x.device)
+        else:
+            out = torch.empty((B, Ho, Wo, Cout), dtype=BF16, device=x.device)
+    if residual is not None and (residual.shape != out.shape or residual.dtype != BF16):
+        raise ValueError("residual must match the output")
+    d = ConvDesc(B, H, W, Cin, Cout, KH, KW, stride, pad, int(relu), int(out_f32_nchw))
+    with torch.cuda.device(x.device):
+        check(lib().pe_conv2d_fwd_bf16(ctypes.addressof(d), x.data_ptr(), w.data_ptr(), _ptr(scale),
+                                       _ptr(shift), _ptr(residual), out.data_ptr(), _stream(x)))
+    return out
+
+
+def deconv4x4s2(x: torch.Tensor, w_phases: torch.Tensor, scale=None, shift=None,
+                relu: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """ConvTranspose2d(k=4, s=2, p=1): x [B,H,W,Cin] -> [B,2H,2W,Cout]."""
+    _check_act(x)
+    B, H, W, Cin = x.shape
+    _, Cout, _, _ = w_phases.shape
+    if tuple(w_phases.shape) != (4, Cout, 4, Cin) or w_phases.dtype != BF16:
+        raise ValueError("w_phases must be bfloat16 [4,Cout,4,Cin]")
+    if out is None:
+        out = torch.empty((B, 2 * H, 2 * W, Cout), dtype=BF16, device=x.device)
+    with torch.cuda.device(x.device):
+        check(lib().pe_deconv4x4s2_fwd_bf16(B, H, W, Cin, Cout, int(relu), x.data_ptr(),
+                                            w_phases.data_ptr(), _ptr(scale), _ptr(shift),
+                                            out.data_ptr(), _stream(x)))
+    return out
+
+
+def stem7x7s2(x_s2d: torch.Tensor, w: torch.Tensor, scale=None, shift=None, relu: bool = True,
+              out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """7x7/2 stem on the space-to-depth image: x_s2d [B,H/2,W/2,16] -> [B,H/2,W/2,Cout]."""
+    _check_act(x_s2d, "x_s2d")
+    B, H2, W2, C = x_s2d.shape
+    Cout = w.shape[0]
+    if C != 16 or tuple(w.shape) != (Cout, 4, 64) or w.dtype != BF16:
+        raise ValueError("stem expects x_s2d [...,16] and w bfloat16 [Cout,4,64]")
+    if out is None:
+        out = torch.empty((B, H2, W2, Cout), dtype=BF16, device=x_s2d.device)
+    with torch.cuda.device(x_s2d.device):
+        check(lib().pe_stem7x7s2_fwd_bf16(B, H2, W2, Cout, int(relu), x_s2d.data_ptr(),
+                                          w.data_ptr(), _ptr(scale), _ptr(shift), out.data_ptr(),
+                                          _stream(x_s2d)))
+    return out
+
+
+IMAGENET_MEAN = (0.485, 0.456, 0.406)
+IMAGENET_STD = (0.229, 0.224, 0.225)
+
+
+def preprocess_u8(img: torch.Tensor, mean=IMAGENET_MEAN, std=IMAGENET_STD,
+                  out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """uint8 [B,H,W,3] -> normalised bf16 space-to-depth [B,H/2,W/2,16]."""
+    _need_gpu(img)
+    if img.dtype != torch.uint8 or img.dim() != 4 or img.shape[3] != 3 or not img.is_contiguous():
+        raise ValueError("img must be contiguous uint8 [B,H,W,3]")
+    B, H, W, _ = img.shape
+    if out is None:
+        out = torch.empty((B, H // 2, W // 2, 16), dtype=BF16, device=img.device)
+    m = (ctypes.c_float * 3)(*mean)
+    s = (ctypes.c_float * 3)(*std)
+    with torch.cuda.device(img.device):
+        check(lib().pe_preprocess_u8_s2d_bf16(img.data_ptr(), B, H, W, ctypes.addressof(m),
+                                              ctypes.addressof(s), out.data_ptr(), _stream(img)))
+    return out
+
+
+def maxpool3x3s2(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _check_act(x)
+    B, H, W, C = x.shape
+    if out is None:
+        out = torch.empty((B, H // 2, W // 2, C), dtype=BF16, device=x.device)
+    with torch.cuda.device(x.device):
+        check(lib().pe_maxpool3x3s2_fwd_bf16(x.data_ptr(), B, H, W, C, out.data_ptr(), _stream(x)))
+    return out

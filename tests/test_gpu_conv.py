@@ -1,0 +1,158 @@
+"""GPU parity of the implicit-GEMM conv / deconv / stem kernels against the torch-CPU float32
+restatement (oracle/torch_oracle.py).
+
+Two kinds of comparison:
+  * small-integer operands, where every product and partial sum is exact in float32, so the
+    bf16 result must match bit for bit whatever the accumulation order (asymmetric weights:
+    a transposed or mis-indexed tile cannot pass);
+  * random bf16 operands with the tolerance |got - ref| <= 4e-3 * max|ref| (one bf16 rounding
+    of the result is 2^-9 relative; fp32 accumulation-order noise is far below that).
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import torch_oracle as to
+from pose_estimation_amd import nn as pnn
+
+pytestmark = pytest.mark.gpu
+BF16 = torch.bfloat16
+TOL = 4e-3
+
+
+def rand_bf16(shape, gen, scale=1.0):
+    return to.bf16r(torch.randn(shape, generator=gen) * scale)
+
+
+def int_tensor(shape, gen, lo, hi):
+    return torch.randint(lo, hi + 1, shape, generator=gen).to(torch.float32)
+
+
+def close(got_bf16_gpu, ref_f32, tol=TOL):
+    got = got_bf16_gpu.float().cpu()
+    err = (got - ref_f32).abs().max().item()
+    ref_max = ref_f32.abs().max().item()
+    assert err <= tol * ref_max + 1e-6, f"max err {err} vs max |ref| {ref_max}"
+
+
+CONV_CASES = [
+    # B, H, W, Cin, Cout, K, stride, pad
+    (2, 16, 12, 64, 64, 1, 1, 0),
+    (2, 16, 12, 64, 256, 1, 1, 0),
+    (2, 16, 12, 256, 64, 1, 1, 0),
+    (2, 16, 12, 64, 64, 3, 1, 1),
+    (3, 16, 12, 128, 128, 3, 2, 1),
+    (2, 16, 12, 256, 512, 1, 2, 0),
+    (1, 8, 6, 512, 512, 3, 1, 1),
+    (5, 7, 5, 64, 192, 3, 1, 1),      # odd sizes, partial tiles in M and N
+    (1, 64, 48, 64, 68, 3, 1, 1),     # N not a multiple of 16
+    (2, 9, 11, 128, 36, 3, 2, 1),     # odd H, W with stride 2; N < 64
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_integer_operands_exact(case):
+    B, H, W, Cin, Cout, K, s, p = case
+    g = torch.Generator().manual_seed(hash(case) % 2**31)
+    x = int_tensor((B, H, W, Cin), g, -2, 2)
+    w = int_tensor((Cout, Cin, K, K), g, -1, 1)
+    ref = to.bf16r(to.conv2d(x, w, stride=s, pad=p))
+    got = pnn.conv2d(x.to(BF16).cuda(), pnn.pack_conv_weight(w).cuda(), stride=s, pad=p)
+    assert got.shape == ref.shape
+    assert torch.equal(got.float().cpu(), ref)
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_random_operands_with_epilogue(case):
+    B, H, W, Cin, Cout, K, s, p = case
+    g = torch.Generator().manual_seed(1 + hash(case) % 2**31)
+    x = rand_bf16((B, H, W, Cin), g)
+    w = rand_bf16((Cout, Cin, K, K), g, (2.0 / (Cin * K * K)) ** 0.5)
+    scale = torch.rand(Cout, generator=g) + 0.5
+    shift = torch.randn(Cout, generator=g) * 0.1
+    Ho = (H + 2 * p - K) // s + 1
+    Wo = (W + 2 * p - K) // s + 1
+    res = rand_bf16((B, Ho, Wo, Cout), g)
+    ref = to.conv2d(x, w, scale, shift, res, s, p, relu=True)
+    got = pnn.conv2d(x.to(BF16).cuda(), pnn.pack_conv_weight(w).cuda(), scale.cuda(), shift.cuda(),
+                     res.to(BF16).cuda(), s, p, relu=True)
+    close(got, ref)
+    # no epilogue at all
+    ref2 = to.conv2d(x, w, stride=s, pad=p)
+    got2 = pnn.conv2d(x.to(BF16).cuda(), pnn.pack_conv_weight(w).cuda(), stride=s, pad=p)
+    close(got2, ref2)
+
+
+def test_conv_f32_nchw_output_with_bias():
+    """The final 1x1 conv: 256 -> 17 channels, float32 NCHW heat maps."""
+    g = torch.Generator().manual_seed(5)
+    B, H, W, Cin, Cout = 3, 64, 48, 256, 17
+    x = rand_bf16((B, H, W, Cin), g)
+    w = rand_bf16((Cout, Cin, 1, 1), g, 0.05)
+    bias = torch.randn(Cout, generator=g) * 0.1
+    ref = to.conv2d(x, w, None, bias).permute(0, 3, 1, 2).contiguous()
+    got = pnn.conv2d(x.to(BF16).cuda(), pnn.pack_conv_weight(w).cuda(), None, bias.cuda(),
+                     out_f32_nchw=True)
+    assert got.dtype == torch.float32 and got.shape == (B, Cout, H, W)
+    err = (got.cpu() - ref).abs().max().item()
+    assert err <= 1e-4 * ref.abs().max().item()  # float32 output: accumulation order only
+    # integer operands: exact
+    xi = int_tensor((B, H, W, Cin), g, -2, 2)
+    wi = int_tensor((Cout, Cin, 1, 1), g, -1, 1)
+    refi = to.conv2d(xi, wi).permute(0, 3, 1, 2).contiguous()
+    goti = pnn.conv2d(xi.to(BF16).cuda(), pnn.pack_conv_weight(wi).cuda(), out_f32_nchw=True)
+    assert torch.equal(goti.cpu(), refi)
+
+
+@pytest.mark.parametrize("case", [(2, 8, 6, 64, 64), (1, 8, 6, 2048, 256), (3, 16, 12, 256, 256),
+                                  (2, 5, 7, 128, 72)])
+def test_deconv_phases(case):
+    B, H, W, Cin, Cout = case
+    g = torch.Generator().manual_seed(7 + Cin)
+    xi = int_tensor((B, H, W, Cin), g, -2, 2)
+    wi = int_tensor((Cin, Cout, 4, 4), g, -1, 1)
+    ref = to.bf16r(to.deconv4x4s2(xi, wi))
+    got = pnn.deconv4x4s2(xi.to(BF16).cuda(), pnn.pack_deconv_weight(wi).cuda())
+    assert got.shape == (B, 2 * H, 2 * W, Cout)
+    assert torch.equal(got.float().cpu(), ref)
+    x = rand_bf16((B, H, W, Cin), g)
+    w = rand_bf16((Cin, Cout, 4, 4), g, (1.0 / (Cin * 4)) ** 0.5)
+    scale = torch.rand(Cout, generator=g) + 0.5
+    shift = torch.randn(Cout, generator=g) * 0.1
+    ref = to.deconv4x4s2(x, w, scale, shift, relu=True)
+    got = pnn.deconv4x4s2(x.to(BF16).cuda(), pnn.pack_deconv_weight(w).cuda(), scale.cuda(),
+                          shift.cuda(), relu=True)
+    close(got, ref)
+
+
+def test_preprocess_and_stem():
+    g = torch.Generator().manual_seed(11)
+    B, H, W = 2, 64, 48
+    img = torch.randint(0, 256, (B, H, W, 3), generator=g, dtype=torch.uint8)
+    xs = pnn.preprocess_u8(img.cuda())
+    x3 = to.preprocess_u8(img.numpy(), pnn.IMAGENET_MEAN, pnn.IMAGENET_STD)
+    want = to.space_to_depth16(x3)
+    assert xs.shape == (B, H // 2, W // 2, 16)
+    assert np.array_equal(xs.float().cpu().numpy(), want)  # bit-exact preprocessing
+    w = rand_bf16((64, 3, 7, 7), g, 0.1)
+    scale = torch.rand(64, generator=g) + 0.5
+    shift = torch.randn(64, generator=g) * 0.1
+    ref = to.conv2d(torch.from_numpy(x3), w, scale, shift, None, 2, 3, relu=True)
+    got = pnn.stem7x7s2(xs, pnn.pack_stem_weight(w).cuda(), scale.cuda(), shift.cuda(), relu=True)
+    assert got.shape == (B, H // 2, W // 2, 64)
+    close(got, ref)
+    # integer image / weights through the stem alone: exact
+    xi = int_tensor((B, H, W, 3), g, -2, 2)
+    wi = int_tensor((64, 3, 7, 7), g, -1, 1)
+    refi = to.bf16r(to.conv2d(xi, wi, stride=2, pad=3))
+    xsi = torch.from_numpy(to.space_to_depth16(xi.numpy())).to(BF16).cuda()
+    goti = pnn.stem7x7s2(xsi, pnn.pack_stem_weight(wi).cuda(), relu=False)
+    assert torch.equal(goti.float().cpu(), refi)
+
+
+def test_maxpool():
+    g = torch.Generator().manual_seed(13)
+    x = rand_bf16((3, 16, 12, 64), g)
+    ref = to.maxpool3x3s2(x)
+    got = pnn.maxpool3x3s2(x.to(BF16).cuda())
+    assert torch.equal(got.float().cpu(), ref)
