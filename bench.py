@@ -188,7 +188,58 @@ class Adam(Workload):
                 "sample": "NumPy oracle, 4M-parameter slice, scaled to 34M"}
 
 
-WORKLOADS = {"decode": Decode, "render": Render, "mse": Mse, "mse_fused": MseFused, "adam": Adam}
+class Infer(Workload):
+    """BASELINE configs[2]: ResNet-50 + 3-deconv inference, 256x192, batch 256, bf16, with the
+    uint8 preprocessing in front and the heat-map decode behind (one step = images -> keypoints)."""
+    name = "resnet50_pose_infer_256x192_b256_bf16"
+    batch = 256
+    dtype = "bf16"
+    bound = "mfma"
+    kernel = "igemm_kernel (all conv/deconv launches of one forward)"
+    peak = 2500.0  # dense bf16 MFMA, TFLOP/s
+
+    def setup(self, device):
+        from pose_estimation_amd import flops, model
+
+        self.net = model.PoseResNet(device)
+        self.net.load_state(model.init_state(self.net.specs, seed=3))
+        macs, _, _ = flops.forward_macs(256, 192)
+        self.flops_per_step = 2.0 * macs * self.batch
+        self.imgs = [torch.from_numpy(synthetic.images_u8(self.batch, 256, 192, seed=1 + i)).to(device)
+                     for i in range(2)]
+
+    def step(self, i):
+        hm = self.net.predict(self.imgs[i % 2])
+        pe.decode(hm)
+
+    def roofline(self, kern_ms):
+        ach = self.flops_per_step / (kern_ms * 1e-3) / 1e12
+        return {"bound": "mfma", "kernel": self.kernel, "achieved": ach, "peak": self.peak,
+                "unit": "TFLOP/s", "frac": ach / self.peak,
+                "flops_per_step": self.flops_per_step, "step_ms": kern_ms, "traffic": None}
+
+    def cpu_baseline(self):
+        from oracle import torch_oracle as to
+        from pose_estimation_amd import model
+        from pose_estimation_amd import nn as pnn
+
+        specs = model.resnet50_pose_specs()
+        state = model.init_state(specs, seed=3)
+        img = synthetic.images_u8(8, 256, 192, seed=1)
+        to.pose_resnet_forward(specs, state, img[:1], pnn.IMAGENET_MEAN, pnn.IMAGENET_STD)
+        times = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            to.pose_resnet_forward(specs, state, img, pnn.IMAGENET_MEAN, pnn.IMAGENET_STD)
+            times.append(time.perf_counter() - t0)
+        med = float(np.median(times))
+        return {"value": 8 / med, "unit": "images/s", "cores": torch.get_num_threads(),
+                "kind": "port",
+                "sample": f"torch-CPU float32 oracle forward, batch 8, median of 3 ({med:.2f} s)"}
+
+
+WORKLOADS = {"decode": Decode, "render": Render, "mse": Mse, "mse_fused": MseFused, "adam": Adam,
+             "infer": Infer}
 
 
 def main() -> None:
@@ -245,7 +296,14 @@ def main() -> None:
     if rank == 0:
         ms_per_step = elapsed * 1e3 / args.steps
         kern_ms = dev_ms / args.steps
-        achieved = wl.bytes_per_step / (kern_ms * 1e-3) / 1e9
+        if hasattr(wl, "roofline"):
+            roof = wl.roofline(kern_ms)
+        else:
+            achieved = wl.bytes_per_step / (kern_ms * 1e-3) / 1e9
+            roof = {"bound": wl.bound, "kernel": wl.kernel, "achieved": achieved,
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                    "bytes_per_launch": wl.bytes_per_step, "launch_ms": kern_ms,
+                    "traffic": None}
         out = {
             "metric": METRIC,
             "value": world * wl.batch * args.steps / elapsed,
@@ -261,10 +319,7 @@ def main() -> None:
             "data": "synthetic",
             "config": {"workload": wl.name, "batch_per_gpu": wl.batch, "joints": K_JOINTS,
                        "heatmap": [H, W], "sharding": "batch, no collective"},
-            "roofline": {"bound": wl.bound, "kernel": wl.kernel, "achieved": achieved,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "bytes_per_launch": wl.bytes_per_step, "launch_ms": kern_ms,
-                         "traffic": None},
+            "roofline": roof,
         }
         # HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE,
         # gfx950-corrected); null when this workload has not been profiled.

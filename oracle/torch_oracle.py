@@ -29,8 +29,15 @@ def _nhwc(x_nchw):
     return x_nchw.permute(0, 2, 3, 1).contiguous()
 
 
-def conv2d(x_nhwc, w_oihw, scale=None, shift=None, residual=None, stride=1, pad=0, relu=False):
-    y = F.conv2d(_nchw(x_nhwc), w_oihw, None, stride=stride, padding=pad)
+def conv2d(x_nhwc, w_oihw, scale=None, shift=None, residual=None, stride=1, pad=0, relu=False,
+           acc64=False):
+    """acc64=True accumulates the dot products in float64 (then rounds to float32): a second
+    accumulation order, used to measure how sensitive a deep bf16 network is to that order."""
+    if acc64:
+        y = F.conv2d(_nchw(x_nhwc).double(), w_oihw.double(), None, stride=stride,
+                     padding=pad).float()
+    else:
+        y = F.conv2d(_nchw(x_nhwc), w_oihw, None, stride=stride, padding=pad)
     if scale is not None:
         y = y * scale.view(1, -1, 1, 1)
     if shift is not None:
@@ -43,8 +50,12 @@ def conv2d(x_nhwc, w_oihw, scale=None, shift=None, residual=None, stride=1, pad=
     return y
 
 
-def deconv4x4s2(x_nhwc, w_iohw, scale=None, shift=None, relu=False):
-    y = F.conv_transpose2d(_nchw(x_nhwc), w_iohw, None, stride=2, padding=1)
+def deconv4x4s2(x_nhwc, w_iohw, scale=None, shift=None, relu=False, acc64=False):
+    if acc64:
+        y = F.conv_transpose2d(_nchw(x_nhwc).double(), w_iohw.double(), None, stride=2,
+                               padding=1).float()
+    else:
+        y = F.conv_transpose2d(_nchw(x_nhwc), w_iohw, None, stride=2, padding=1)
     if scale is not None:
         y = y * scale.view(1, -1, 1, 1)
     if shift is not None:
@@ -78,3 +89,48 @@ def space_to_depth16(x_nhwc3: np.ndarray) -> np.ndarray:
 
 def maxpool3x3s2(x_nhwc):
     return _nhwc(F.max_pool2d(_nchw(x_nhwc), 3, 2, 1))
+
+
+def pose_resnet_forward(specs, state, img_u8: np.ndarray, mean, std, bn_eps: float = 1e-5,
+                        acc64: bool = False):
+    """Inference forward of the ResNet + 3-deconv pose net on the CPU, float32 accumulation,
+    with operands rounded to bf16 at the points where the kernels store bf16: the weights, the
+    preprocessed image and every layer output except the final heat maps.
+
+    specs: (stem, blocks, deconvs, final) from pose_estimation_amd.model.resnet50_pose_specs
+    (plain dataclasses; no device code runs).  state: framework-layout float32 tensors.
+    Returns float32 heat maps [B,K,H/4,W/4].
+
+    A deep bf16 network amplifies the choice of float32 accumulation order (an order change
+    flips an occasional bf16 rounding, and later layers magnify it), so an end-to-end bound
+    is stated against the spread between acc64=False and acc64=True of this same function.
+    """
+    stem, blocks, deconvs, final = specs
+
+    def fold(c):
+        if not c.bn:
+            return None, state[c.name + ".bias"]
+        sc = state[c.name + ".bn.gamma"] / torch.sqrt(state[c.name + ".bn.var"] + bn_eps)
+        return sc, state[c.name + ".bn.beta"] - state[c.name + ".bn.mean"] * sc
+
+    def conv(c, x, residual=None, relu=None):
+        sc, sh = fold(c)
+        w = bf16r(state[c.name + ".weight"])
+        return bf16r(conv2d(x, w, sc, sh, residual, c.stride, c.pad,
+                            c.relu if relu is None else relu, acc64=acc64))
+
+    x = torch.from_numpy(preprocess_u8(img_u8, mean, std))
+    x = conv(stem, x)
+    x = maxpool3x3s2(x)
+    for b in blocks:
+        o = conv(b.c1, x)
+        o = conv(b.c2, o)
+        idn = conv(b.down, x) if b.down else x
+        x = conv(b.c3, o, residual=idn, relu=True)
+    for d in deconvs:
+        sc, sh = fold(d)
+        x = bf16r(deconv4x4s2(x, bf16r(state[d.name + ".weight"]), sc, sh, relu=True,
+                              acc64=acc64))
+    sc, sh = fold(final)
+    y = conv2d(x, bf16r(state[final.name + ".weight"]), sc, sh, acc64=acc64)
+    return y.permute(0, 3, 1, 2).contiguous()

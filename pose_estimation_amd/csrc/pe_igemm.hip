@@ -161,6 +161,76 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
                            p.OH == p.Ho && p.OW == p.Wo);
     const int OHW = p.OH * p.OW;
     const int nq = (lane >> 4) * 4;
+
+    // Fast path (bf16 NHWC, channel count a multiple of 8): the scaled fp32 tile goes through
+    // LDS (free after the K loop) so that global traffic is whole 16-byte chunks, 256 B (BN=128)
+    // contiguous per pixel: residual loads and output stores become full-line accesses.
+    // Row pitch BN + 4 floats keeps the 8-lane groups of ds_write_b128 on distinct banks.
+    if (p.out_mode == 0 && (p.N & 7) == 0 && (p.ldc & 7) == 0) {
+        constexpr int CP = BN + 4;
+        float* cs = reinterpret_cast<float*>(smem);
+#pragma unroll
+        for (int a = 0; a < TN; ++a) {
+            const int col = wave_n * (BN / 2) + a * 16 + nq;
+            const int n = n0 + col;
+            f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+            if (n < p.N) {
+                if (p.scale) sc = *reinterpret_cast<const f32x4*>(p.scale + n);
+                if (p.shift) sh = *reinterpret_cast<const f32x4*>(p.shift + n);
+            }
+#pragma unroll
+            for (int b = 0; b < TM; ++b) {
+                const int pr = wave_m * 64 + b * 16 + lr;
+                *reinterpret_cast<f32x4*>(cs + pr * CP + col) = acc[a][b] * sc + sh;
+            }
+        }
+        __syncthreads();
+        constexpr int CPR = BN / 8;       // 16-byte output chunks per pixel row
+        constexpr int RPP = 256 / CPR;    // pixel rows per pass
+        const int chunk = tid % CPR;
+        const int prow = tid / CPR;
+        const int n = n0 + chunk * 8;
+        if (n < p.N) {
+#pragma unroll
+            for (int pass = 0; pass < BM / RPP; ++pass) {
+                const int pr = prow + pass * RPP;
+                const long m = m0 + pr;
+                if (m >= M) break;
+                long opix = m;
+                if (!identity) {
+                    const int bb = (int)(m / HoWo);
+                    const int rem = (int)(m - (long)bb * HoWo);
+                    const int oy = rem / p.Wo;
+                    const int ox = rem - oy * p.Wo;
+                    opix = (long)bb * OHW + (oy * p.osy + p.ooy) * p.OW + ox * p.osx + p.oox;
+                }
+                const f32x4 v0 = *reinterpret_cast<const f32x4*>(cs + pr * CP + chunk * 8);
+                const f32x4 v1 = *reinterpret_cast<const f32x4*>(cs + pr * CP + chunk * 8 + 4);
+                float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+                if (p.res) {
+                    const uint4 rv = *reinterpret_cast<const uint4*>(p.res + opix * p.ldc + n);
+                    const uint32_t u[4] = {rv.x, rv.y, rv.z, rv.w};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        v[2 * i] += bf16_bits_to_float(u[i] & 0xffffu);
+                        v[2 * i + 1] += bf16_bits_to_float(u[i] >> 16);
+                    }
+                }
+                if (p.relu) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[i] = fmaxf(v[i], 0.0f);
+                }
+                uint4 o;
+                o.x = pack_bf16x2(v[0], v[1]);
+                o.y = pack_bf16x2(v[2], v[3]);
+                o.z = pack_bf16x2(v[4], v[5]);
+                o.w = pack_bf16x2(v[6], v[7]);
+                *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(p.y) + opix * p.ldc + n) = o;
+            }
+        }
+        return;
+    }
+
 #pragma unroll
     for (int b = 0; b < TM; ++b) {
         const long m = m0 + wave_m * 64 + b * 16 + lr;
@@ -240,7 +310,8 @@ int32_t igemm_launch(const IgemmParams& p, hipStream_t st, const char* what) {
                what, p.Cx);
     PE_REQUIRE(p.T >= 1 && p.T <= kMaxTaps, PE_E_UNSUPPORTED, "%s: %d taps (max %d)", what, p.T,
                kMaxTaps);
-    PE_REQUIRE(aligned(p.x, 16) && aligned(p.w, 16) && aligned(p.y, 8) && aligned(p.res, 8),
+    PE_REQUIRE(aligned(p.x, 16) && aligned(p.w, 16) && aligned(p.y, 16) && aligned(p.res, 16) &&
+                   aligned(p.scale, 16) && aligned(p.shift, 16),
                PE_E_INVALID, "%s: tensors must be 16-byte aligned", what);
     PE_REQUIRE(p.out_mode == 1 || p.ldc % 4 == 0, PE_E_UNSUPPORTED,
                "%s: output channel pitch must be a multiple of 4", what);

@@ -1,0 +1,242 @@
+"""ResNet-50 "simple baseline" pose network (3 deconv head, K heat maps) on the HIP kernels.
+
+The reference's network files (nets/mobilenet_v2.py, model/mobilenet_pose.py;
+PoseEstimation.pyproj:31-32) are absent; the architecture here is the one the build's
+north star names: ResNet-50 v1 bottlenecks with the stride on the 3x3, three
+ConvTranspose(4x4, s2, p1, 256) + BN + ReLU, and a 1x1 conv to K joints.
+
+Parameters live in one flat float32 arena (master copy) with a bf16 working copy of the same
+layout; every weight view is in the packed layout its kernel reads.  torch is used for
+buffers, views and the one-off BN folding only.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from . import nn as pnn
+from . import ops
+
+BF16 = torch.bfloat16
+BN_EPS = 1e-5
+
+
+@dataclass
+class ConvSpec:
+    name: str
+    kind: str            # "stem" | "conv" | "deconv" | "final"
+    cin: int
+    cout: int
+    k: int
+    stride: int
+    pad: int
+    bn: bool             # followed by batch norm (else plain bias)
+    relu: bool
+
+
+@dataclass
+class BlockSpec:
+    c1: ConvSpec
+    c2: ConvSpec
+    c3: ConvSpec
+    down: Optional[ConvSpec]
+
+
+def resnet50_pose_specs(num_joints: int = 17, layers=(3, 4, 6, 3), width: int = 64,
+                        head_ch: int = 256):
+    """(stem, blocks, deconvs, final) layer specs.  `width` scales every channel count
+    (64 = ResNet-50); tests use narrower nets."""
+    stem = ConvSpec("stem", "stem", 3, width, 7, 2, 3, True, True)
+    blocks: List[BlockSpec] = []
+    cin = width
+    for li, n in enumerate(layers):
+        mid = width * (2 ** li)
+        cout = mid * 4
+        for bi in range(n):
+            s = 2 if (bi == 0 and li > 0) else 1
+            p = f"layer{li + 1}.{bi}"
+            c1 = ConvSpec(p + ".conv1", "conv", cin, mid, 1, 1, 0, True, True)
+            c2 = ConvSpec(p + ".conv2", "conv", mid, mid, 3, s, 1, True, True)
+            c3 = ConvSpec(p + ".conv3", "conv", mid, cout, 1, 1, 0, True, True)  # relu after add
+            down = None
+            if bi == 0:
+                down = ConvSpec(p + ".down", "conv", cin, cout, 1, s, 0, True, False)
+            blocks.append(BlockSpec(c1, c2, c3, down))
+            cin = cout
+    deconvs = []
+    for i in range(3):
+        deconvs.append(ConvSpec(f"deconv{i + 1}", "deconv", cin, head_ch, 4, 2, 1, True, True))
+        cin = head_ch
+    final = ConvSpec("final", "final", cin, num_joints, 1, 1, 0, False, False)
+    return stem, blocks, deconvs, final
+
+
+def all_convs(specs) -> List[ConvSpec]:
+    stem, blocks, deconvs, final = specs
+    out = [stem]
+    for b in blocks:
+        out += [b.c1, b.c2, b.c3] + ([b.down] if b.down else [])
+    return out + deconvs + [final]
+
+
+def framework_shape(c: ConvSpec) -> Tuple[int, ...]:
+    if c.kind == "deconv":
+        return (c.cin, c.cout, 4, 4)          # ConvTranspose2d layout
+    return (c.cout, c.cin, c.k, c.k)
+
+
+def packed_shape(c: ConvSpec) -> Tuple[int, ...]:
+    if c.kind == "stem":
+        return (c.cout, 4, 64)
+    if c.kind == "deconv":
+        return (4, c.cout, 4, c.cin)
+    return (c.cout, c.k, c.k, c.cin)
+
+
+def pack_weight(c: ConvSpec, w: torch.Tensor) -> torch.Tensor:
+    """Framework-layout float32 weight -> packed layout (still float32)."""
+    if c.kind == "stem":
+        return pnn.pack_stem_weight(w.float()).float()
+    if c.kind == "deconv":
+        return pnn.pack_deconv_weight(w.float()).float()
+    return w.permute(0, 2, 3, 1).contiguous()
+
+
+def init_state(specs, seed: int = 3) -> Dict[str, torch.Tensor]:
+    """Random-init state dict in framework layouts (CPU float32): He-normal convs, BN gamma 1 /
+    beta 0 / running (0, 1), deconv and final conv N(0, 0.001), zero bias."""
+    g = torch.Generator().manual_seed(seed)
+    st: Dict[str, torch.Tensor] = {}
+    for c in all_convs(specs):
+        shape = framework_shape(c)
+        if c.kind in ("deconv", "final"):
+            w = torch.randn(shape, generator=g) * 0.001
+        else:
+            fan_out = c.cout * c.k * c.k
+            w = torch.randn(shape, generator=g) * (2.0 / fan_out) ** 0.5
+        st[c.name + ".weight"] = w
+        if c.bn:
+            st[c.name + ".bn.gamma"] = torch.ones(c.cout)
+            st[c.name + ".bn.beta"] = torch.zeros(c.cout)
+            st[c.name + ".bn.mean"] = torch.zeros(c.cout)
+            st[c.name + ".bn.var"] = torch.ones(c.cout)
+        else:
+            st[c.name + ".bias"] = torch.zeros(c.cout)
+    return st
+
+
+def randomize_bn(state: Dict[str, torch.Tensor], seed: int = 5) -> None:
+    """Give every BN non-trivial statistics (used by tests so folding is exercised)."""
+    g = torch.Generator().manual_seed(seed)
+    for k in list(state):
+        n = state[k].numel()
+        if k.endswith(".bn.gamma"):
+            state[k] = torch.rand(n, generator=g) + 0.5
+        elif k.endswith(".bn.beta") or k.endswith(".bias"):
+            state[k] = torch.randn(n, generator=g) * 0.1
+        elif k.endswith(".bn.mean"):
+            state[k] = torch.randn(n, generator=g) * 0.1
+        elif k.endswith(".bn.var"):
+            state[k] = torch.rand(n, generator=g) + 0.5
+
+
+def _align8(n: int) -> int:
+    return (n + 7) // 8 * 8
+
+
+class PoseResNet:
+    """The network with its parameter arenas on one GPU."""
+
+    def __init__(self, device, num_joints: int = 17, layers=(3, 4, 6, 3), width: int = 64,
+                 head_ch: int = 256):
+        self.device = torch.device(device)
+        self.num_joints = num_joints
+        self.specs = resnet50_pose_specs(num_joints, layers, width, head_ch)
+        self.convs = all_convs(self.specs)
+        # ---- arena layout: every tensor starts on an 8-element boundary
+        self.offsets: Dict[str, Tuple[int, Tuple[int, ...]]] = {}
+        off = 0
+        for c in self.convs:
+            shp = packed_shape(c)
+            self.offsets[c.name + ".weight"] = (off, shp)
+            off += _align8(int(torch.tensor(shp).prod()))
+            names = (".bn.gamma", ".bn.beta") if c.bn else (".bias",)
+            for nm in names:
+                self.offsets[c.name + nm] = (off, (c.cout,))
+                off += _align8(c.cout)
+        self.n_params = off
+        self.master = torch.zeros(off, dtype=torch.float32, device=self.device)
+        self.work = torch.zeros(off, dtype=BF16, device=self.device)
+        self.bn_mean = {c.name: torch.zeros(c.cout, device=self.device) for c in self.convs if c.bn}
+        self.bn_var = {c.name: torch.ones(c.cout, device=self.device) for c in self.convs if c.bn}
+        self.scale: Dict[str, Optional[torch.Tensor]] = {}
+        self.shift: Dict[str, Optional[torch.Tensor]] = {}
+
+    # ------------------------------------------------------------------ parameters
+    def view(self, arena: torch.Tensor, name: str) -> torch.Tensor:
+        off, shp = self.offsets[name]
+        n = 1
+        for s in shp:
+            n *= s
+        return arena[off:off + n].view(shp)
+
+    def load_state(self, state: Dict[str, torch.Tensor]) -> None:
+        """Copy a framework-layout state dict into the arenas (packing every weight)."""
+        for c in self.convs:
+            w = pack_weight(c, state[c.name + ".weight"])
+            self.view(self.master, c.name + ".weight").copy_(w.to(self.device))
+            if c.bn:
+                self.view(self.master, c.name + ".bn.gamma").copy_(state[c.name + ".bn.gamma"])
+                self.view(self.master, c.name + ".bn.beta").copy_(state[c.name + ".bn.beta"])
+                self.bn_mean[c.name].copy_(state[c.name + ".bn.mean"])
+                self.bn_var[c.name].copy_(state[c.name + ".bn.var"])
+            else:
+                self.view(self.master, c.name + ".bias").copy_(state[c.name + ".bias"])
+        self.work.copy_(self.master)  # one rounding to bf16
+        self.fold_bn()
+
+    def fold_bn(self) -> None:
+        """Inference epilogue constants: scale = gamma/sqrt(var+eps), shift = beta - mean*scale."""
+        for c in self.convs:
+            if c.bn:
+                gamma = self.view(self.master, c.name + ".bn.gamma")
+                beta = self.view(self.master, c.name + ".bn.beta")
+                sc = gamma / torch.sqrt(self.bn_var[c.name] + BN_EPS)
+                self.scale[c.name] = sc.contiguous()
+                self.shift[c.name] = (beta - self.bn_mean[c.name] * sc).contiguous()
+            else:
+                self.scale[c.name] = None
+                self.shift[c.name] = self.view(self.master, c.name + ".bias").clone()
+
+    def w(self, c: ConvSpec) -> torch.Tensor:
+        return self.view(self.work, c.name + ".weight")
+
+    # ------------------------------------------------------------------ inference
+    def _conv(self, c: ConvSpec, x, residual=None, relu=None, **kw):
+        return pnn.conv2d(x, self.w(c), self.scale[c.name], self.shift[c.name], residual,
+                          c.stride, c.pad, c.relu if relu is None else relu, **kw)
+
+    def forward_features(self, x_s2d: torch.Tensor) -> torch.Tensor:
+        stem, blocks, deconvs, final = self.specs
+        x = pnn.stem7x7s2(x_s2d, self.w(stem), self.scale[stem.name], self.shift[stem.name], True)
+        x = pnn.maxpool3x3s2(x)
+        for b in blocks:
+            o = self._conv(b.c1, x)
+            o = self._conv(b.c2, o)
+            idn = self._conv(b.down, x) if b.down else x
+            x = self._conv(b.c3, o, residual=idn, relu=True)
+        for d in deconvs:
+            x = pnn.deconv4x4s2(x, self.w(d), self.scale[d.name], self.shift[d.name], True)
+        return x
+
+    def predict(self, images_u8: torch.Tensor) -> torch.Tensor:
+        """uint8 [B,H,W,3] -> float32 heat maps [B,K,H/4,W/4] (inference, folded BN)."""
+        final = self.specs[3]
+        x = pnn.preprocess_u8(images_u8)
+        x = self.forward_features(x)
+        return self._conv(final, x, out_f32_nchw=True)
+
+    def predict_and_decode(self, images_u8: torch.Tensor):
+        return ops.decode(self.predict(images_u8))
