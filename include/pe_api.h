@@ -200,6 +200,75 @@ int32_t pe_preprocess_u8_s2d_bf16(const uint8_t* img, int32_t B, int32_t H, int3
 int32_t pe_maxpool3x3s2_fwd_bf16(const void* x, int32_t B, int32_t H, int32_t W, int32_t C,
                                  void* y, pe_stream_t stream);
 
+/* Backward of the pool above: dx [B,H,W,C] from x [B,H,W,C] and dy [B,H/2,W/2,C]; a tie inside
+ * a window sends the gradient to its first maximum (row-major scan). */
+int32_t pe_maxpool3x3s2_bwd_bf16(const void* x, const void* dy, int32_t B, int32_t H, int32_t W,
+                                 int32_t C, void* dx, pe_stream_t stream);
+
+/* Backward-data.  d describes the FORWARD conv (stride 1 or 2); dy is [B,Ho,Wo,Cout] bf16;
+ * w_t is the transposed weight [Cin][KH*KW][Cout] bf16 (see pe_transpose_weights_bf16);
+ * dx [B,H,W,Cin] bf16 = conv_bwd_data(dy) (+ residual, same shape as dx, may be NULL). */
+int32_t pe_conv2d_bwd_data_bf16(const pe_conv_desc* d, const void* dy, const void* w_t,
+                                const void* residual, void* dx, pe_stream_t stream);
+
+/* Backward-data of the 4x4/2 transposed conv: dy [B,2H,2W,Cout], w_t [Cin][16][Cout] where
+ * slot = phase*4 + tap of the forward packing; dx [B,H,W,Cin]. */
+int32_t pe_deconv4x4s2_bwd_data_bf16(int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout,
+                                     const void* dy, const void* w_t, void* dx,
+                                     pe_stream_t stream);
+
+/* Backward-weight: dw (float32, same layout as the packed forward weight) += x (*) dy.
+ * The caller zeroes dw; partial sums from different pixel ranges are combined with float32
+ * atomics.  ldy = channels per pixel of dy (>= Cout rounded up to 8; lets a zero-padded
+ * gradient of a narrow layer be used). */
+int32_t pe_conv2d_bwd_weight_bf16(const pe_conv_desc* d, const void* x, const void* dy,
+                                  int32_t ldy, float* dw, pe_stream_t stream);
+int32_t pe_deconv4x4s2_bwd_weight_bf16(int32_t B, int32_t H, int32_t W, int32_t Cin,
+                                       int32_t Cout, const void* x, const void* dy,
+                                       float* dw_phases, pe_stream_t stream);
+int32_t pe_stem7x7s2_bwd_weight_bf16(int32_t B, int32_t H2, int32_t W2, int32_t Cout,
+                                     const void* x_s2d, const void* dy, float* dw,
+                                     pe_stream_t stream);
+
+/* out[c][t0 + t][a] = in[a][t][c] (bf16), out rows are slots*apitch elements long.  Builds the
+ * backward-data weight layouts from the forward packings. */
+int32_t pe_transpose_weights_bf16(const void* in, int32_t A, int32_t T, int32_t C, void* out,
+                                  int32_t slots, int32_t apitch, int32_t t0, pe_stream_t stream);
+
+/* Loss-gradient hand-over: float32 [B][K][HW] -> bf16 [B*HW][Kpad] (zero padded), and
+ * dbias[k] += sum over pixels (dbias may be NULL; the caller zeroes it). */
+int32_t pe_final_grad_prepare_bf16(const float* g_nchw, int32_t B, int32_t K, int32_t HW,
+                                   int32_t Kpad, void* out_nhwc, float* dbias,
+                                   pe_stream_t stream);
+
+/* a[i] *= b[i] (float32); used to keep structurally-zero packed weights at zero gradient. */
+int32_t pe_mul_f32(float* a, const float* b, int64_t n, pe_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * Batch normalisation in training mode over NHWC bf16 viewed as [M][C], M = B*H*W.
+ * Replaces: the batch-norm layers of nets/mobilenet_v2.py (PoseEstimation.pyproj:32; absent).
+ *   stats : mean/var (biased) of z per channel -> mean, rstd = 1/sqrt(var+eps),
+ *           scale = gamma*rstd, shift = beta - mean*scale; running buffers (may be NULL)
+ *           move by `momentum` towards (mean, unbiased var).
+ *   apply : y = relu?( z*scale + shift (+ residual) ) in bf16.
+ *   bwd   : g = da masked by (a > 0) when a != NULL; dbeta = sum g; dgamma = sum g*xhat;
+ *           dz = gamma*rstd*(g - dbeta/M - xhat*dgamma/M); dmasked (may be NULL) receives g.
+ * C must be 8 * a power of two, at most 2048.  workspace: pe_bn_workspace_bytes(M, C).
+ * Reductions are ordered: results are bit-stable from run to run.
+ * ---------------------------------------------------------------------- */
+size_t pe_bn_workspace_bytes(int64_t M, int32_t C);
+int32_t pe_bn_stats_bf16(const void* z, int64_t M, int32_t C, const float* gamma,
+                         const float* beta, float eps, float momentum, float* running_mean,
+                         float* running_var, float* mean, float* rstd, float* scale,
+                         float* shift, void* workspace, pe_stream_t stream);
+int32_t pe_bn_apply_bf16(const void* z, int64_t M, int32_t C, const float* scale,
+                         const float* shift, const void* residual, int32_t relu, void* y,
+                         pe_stream_t stream);
+int32_t pe_bn_bwd_bf16(const void* da, const void* a, const void* z, int64_t M, int32_t C,
+                       const float* gamma, const float* mean, const float* rstd, float* dgamma,
+                       float* dbeta, void* dz, void* dmasked, void* workspace,
+                       pe_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

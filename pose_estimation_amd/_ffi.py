@@ -82,6 +82,49 @@ SIGNATURES = {
     "pe_maxpool3x3s2_fwd_bf16": (
         c_int32, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p],
     ),
+    "pe_maxpool3x3s2_bwd_bf16": (
+        c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p],
+    ),
+    "pe_conv2d_bwd_data_bf16": (
+        c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
+    ),
+    "pe_deconv4x4s2_bwd_data_bf16": (
+        c_int32,
+        [c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p],
+    ),
+    "pe_conv2d_bwd_weight_bf16": (
+        c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p],
+    ),
+    "pe_deconv4x4s2_bwd_weight_bf16": (
+        c_int32,
+        [c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p],
+    ),
+    "pe_stem7x7s2_bwd_weight_bf16": (
+        c_int32, [c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p],
+    ),
+    "pe_transpose_weights_bf16": (
+        c_int32,
+        [c_void_p, c_int32, c_int32, c_int32, c_void_p, c_int32, c_int32, c_int32, c_void_p],
+    ),
+    "pe_final_grad_prepare_bf16": (
+        c_int32, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p],
+    ),
+    "pe_mul_f32": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p]),
+    "pe_bn_workspace_bytes": (c_size_t, [c_int64, c_int32]),
+    "pe_bn_stats_bf16": (
+        c_int32,
+        [c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_float, c_float, c_void_p, c_void_p,
+         c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
+    ),
+    "pe_bn_apply_bf16": (
+        c_int32,
+        [c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p],
+    ),
+    "pe_bn_bwd_bf16": (
+        c_int32,
+        [c_void_p, c_void_p, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_void_p,
+         c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
+    ),
 }
 
 

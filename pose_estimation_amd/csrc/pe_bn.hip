@@ -1,0 +1,324 @@
+// Batch normalisation for training, over NHWC bf16 tensors viewed as [M][C] (M = B*H*W).
+//
+// Bound: HBM bandwidth.  Forward: one reduction pass over z (sum, sum of squares per channel),
+// a finalize launch, one element-wise pass (normalise + residual + ReLU).  Backward: one
+// reduction pass (sum g, sum g*z with g = da masked by the ReLU), a finalize launch, one
+// element-wise pass producing dz (and g itself when the residual branch needs it).
+// Reductions are two-stage and ordered (per-block partials in the workspace, folded by one
+// workgroup), so results are bit-stable from run to run.  Every access is 16 bytes.
+#include <math.h>
+
+#include "pe_common.h"
+
+namespace pe {
+
+constexpr int kBnMaxBlocks = 1024;
+
+struct BnGeom {
+    int cg;         // 16-byte channel groups per row (C / 8)
+    int rl;         // rows a workgroup walks in parallel (256 / cg)
+    int rows_blk;   // rows per workgroup
+    int nblk;       // workgroups
+};
+
+static BnGeom bn_geom(long M, int C) {
+    BnGeom g;
+    g.cg = C / 8;
+    g.rl = 256 / g.cg;
+    long rows = (M + kBnMaxBlocks - 1) / kBnMaxBlocks;
+    rows = (rows + g.rl - 1) / g.rl * g.rl;
+    if (rows < (long)g.rl * 4) rows = (long)g.rl * 4;
+    g.rows_blk = (int)rows;
+    g.nblk = (int)((M + rows - 1) / rows);
+    return g;
+}
+
+__device__ __forceinline__ void unpack8(const uint4& v, float* f) {
+    const uint32_t u[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        f[2 * i] = bf16_bits_to_float(u[i] & 0xffffu);
+        f[2 * i + 1] = bf16_bits_to_float(u[i] >> 16);
+    }
+}
+
+__device__ __forceinline__ uint4 pack8(const float* f) {
+    uint4 o;
+    o.x = float_to_bf16_bits(f[0]) | (float_to_bf16_bits(f[1]) << 16);
+    o.y = float_to_bf16_bits(f[2]) | (float_to_bf16_bits(f[3]) << 16);
+    o.z = float_to_bf16_bits(f[4]) | (float_to_bf16_bits(f[5]) << 16);
+    o.w = float_to_bf16_bits(f[6]) | (float_to_bf16_bits(f[7]) << 16);
+    return o;
+}
+
+// MODE 0: s1 = sum z, s2 = sum z*z.   MODE 1: g = da * (a > 0 if a given); s1 = sum g, s2 = sum g*z.
+// partial layout: [nblk][2][C].
+template <int MODE>
+__global__ __launch_bounds__(256) void bn_reduce_kernel(const uint16_t* __restrict__ z,
+                                                        const uint16_t* __restrict__ da,
+                                                        const uint16_t* __restrict__ a, long M,
+                                                        int C, BnGeom g,
+                                                        float* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* red = reinterpret_cast<float*>(smem);  // [rl][2][C]
+    const int tid = threadIdx.x;
+    const int cgi = tid % g.cg;
+    const int rli = tid / g.cg;
+    const long row0 = (long)blockIdx.x * g.rows_blk;
+    long row1 = row0 + g.rows_blk;
+    if (row1 > M) row1 = M;
+    float s1[8], s2[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s1[i] = s2[i] = 0.0f;
+    for (long r = row0 + rli; r < row1; r += g.rl) {
+        const long off = r * C + cgi * 8;
+        float zf[8];
+        unpack8(*reinterpret_cast<const uint4*>(z + off), zf);
+        if (MODE == 0) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                s1[i] += zf[i];
+                s2[i] += zf[i] * zf[i];
+            }
+        } else {
+            float gf[8];
+            unpack8(*reinterpret_cast<const uint4*>(da + off), gf);
+            if (a) {
+                float af[8];
+                unpack8(*reinterpret_cast<const uint4*>(a + off), af);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) gf[i] = af[i] > 0.0f ? gf[i] : 0.0f;
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                s1[i] += gf[i];
+                s2[i] += gf[i] * zf[i];
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        red[(rli * 2 + 0) * C + cgi * 8 + i] = s1[i];
+        red[(rli * 2 + 1) * C + cgi * 8 + i] = s2[i];
+    }
+    __syncthreads();
+    for (int e = tid; e < 2 * C; e += 256) {
+        float t = 0.0f;
+        for (int r = 0; r < g.rl; ++r) t += red[r * 2 * C + e];
+        partial[(long)blockIdx.x * 2 * C + e] = t;
+    }
+}
+
+struct BnFwdOut {
+    float *mean, *rstd, *scale, *shift, *running_mean, *running_var;
+};
+
+__global__ __launch_bounds__(256) void bn_fwd_finalize_kernel(const float* __restrict__ partial,
+                                                              int nblk, int C, float inv_m,
+                                                              float unbias, const float* gamma,
+                                                              const float* beta, float eps,
+                                                              float momentum, BnFwdOut o) {
+    for (int c = blockIdx.x * 256 + threadIdx.x; c < C; c += gridDim.x * 256) {
+        float s1 = 0.0f, s2 = 0.0f;
+        for (int b = 0; b < nblk; ++b) {
+            s1 += partial[(long)b * 2 * C + c];
+            s2 += partial[(long)b * 2 * C + C + c];
+        }
+        const float mean = s1 * inv_m;
+        float var = s2 * inv_m - mean * mean;
+        var = fmaxf(var, 0.0f);
+        const float rstd = 1.0f / sqrtf(var + eps);
+        const float sc = gamma[c] * rstd;
+        o.mean[c] = mean;
+        o.rstd[c] = rstd;
+        o.scale[c] = sc;
+        o.shift[c] = beta[c] - mean * sc;
+        if (o.running_mean) {
+            o.running_mean[c] = (1.0f - momentum) * o.running_mean[c] + momentum * mean;
+            o.running_var[c] = (1.0f - momentum) * o.running_var[c] + momentum * (var * unbias);
+        }
+    }
+}
+
+// dz = A*(g - Bc - (z - mean)*Cc) with A = gamma*rstd, Bc = sum(g)/M, Cc = dgamma*rstd/M.
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ partial,
+                                                              int nblk, int C, float inv_m,
+                                                              const float* gamma,
+                                                              const float* mean,
+                                                              const float* rstd, float* dgamma,
+                                                              float* dbeta, float* coefA,
+                                                              float* coefB, float* coefC) {
+    for (int c = blockIdx.x * 256 + threadIdx.x; c < C; c += gridDim.x * 256) {
+        float s1 = 0.0f, s2 = 0.0f;
+        for (int b = 0; b < nblk; ++b) {
+            s1 += partial[(long)b * 2 * C + c];
+            s2 += partial[(long)b * 2 * C + C + c];
+        }
+        const float dg = (s2 - mean[c] * s1) * rstd[c];
+        dgamma[c] = dg;
+        dbeta[c] = s1;
+        coefA[c] = gamma[c] * rstd[c];
+        coefB[c] = s1 * inv_m;
+        coefC[c] = dg * rstd[c] * inv_m;
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_apply_kernel(const uint16_t* __restrict__ z, long nchunk,
+                                                       int cg, const float* __restrict__ scale,
+                                                       const float* __restrict__ shift,
+                                                       const uint16_t* __restrict__ res, int relu,
+                                                       uint16_t* __restrict__ y) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nchunk; i += (long)gridDim.x * 256) {
+        const int c0 = (int)(i % cg) * 8;
+        float v[8];
+        unpack8(*reinterpret_cast<const uint4*>(z + i * 8), v);
+        const f32x4 s0 = *reinterpret_cast<const f32x4*>(scale + c0);
+        const f32x4 s1 = *reinterpret_cast<const f32x4*>(scale + c0 + 4);
+        const f32x4 h0 = *reinterpret_cast<const f32x4*>(shift + c0);
+        const f32x4 h1 = *reinterpret_cast<const f32x4*>(shift + c0 + 4);
+        const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+        const float sh[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = v[k] * sc[k] + sh[k];
+        if (res) {
+            float r[8];
+            unpack8(*reinterpret_cast<const uint4*>(res + i * 8), r);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] += r[k];
+        }
+        if (relu) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k], 0.0f);
+        }
+        *reinterpret_cast<uint4*>(y + i * 8) = pack8(v);
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
+    const uint16_t* __restrict__ da, const uint16_t* __restrict__ a, const uint16_t* __restrict__ z,
+    long nchunk, int cg, const float* __restrict__ mean, const float* __restrict__ coefA,
+    const float* __restrict__ coefB, const float* __restrict__ coefC, uint16_t* __restrict__ dz,
+    uint16_t* __restrict__ dmasked) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nchunk; i += (long)gridDim.x * 256) {
+        const int c0 = (int)(i % cg) * 8;
+        float g[8], zf[8];
+        unpack8(*reinterpret_cast<const uint4*>(da + i * 8), g);
+        unpack8(*reinterpret_cast<const uint4*>(z + i * 8), zf);
+        if (a) {
+            float af[8];
+            unpack8(*reinterpret_cast<const uint4*>(a + i * 8), af);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) g[k] = af[k] > 0.0f ? g[k] : 0.0f;
+        }
+        if (dmasked) *reinterpret_cast<uint4*>(dmasked + i * 8) = pack8(g);
+        float o[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int c = c0 + k;
+            o[k] = coefA[c] * (g[k] - coefB[c] - (zf[k] - mean[c]) * coefC[c]);
+        }
+        *reinterpret_cast<uint4*>(dz + i * 8) = pack8(o);
+    }
+}
+
+static unsigned ew_grid(long nchunk) {
+    long b = (nchunk + 255) / 256;
+    if (b > 256 * 16) b = 256 * 16;
+    if (b < 1) b = 1;
+    return (unsigned)b;
+}
+
+static int32_t bn_check(const char* what, long M, int C) {
+    PE_REQUIRE(M > 0 && C > 0, PE_E_INVALID, "%s: M and C must be positive", what);
+    PE_REQUIRE(C % 8 == 0 && C <= 2048 && 256 % (C / 8) == 0, PE_E_UNSUPPORTED,
+               "%s: C must be 8 * a power of two, at most 2048 (C = %d)", what, C);
+    return PE_OK;
+}
+
+}  // namespace pe
+
+using namespace pe;
+
+extern "C" size_t pe_bn_workspace_bytes(int64_t M, int32_t C) {
+    if (M <= 0 || C <= 0 || C % 8 != 0 || C > 2048 || 256 % (C / 8) != 0) return 16;
+    // per-block partials + three per-channel coefficient rows for the backward pass
+    return ((size_t)kBnMaxBlocks * 2 + 3) * (size_t)C * sizeof(float);
+}
+
+extern "C" int32_t pe_bn_stats_bf16(const void* z, int64_t M, int32_t C, const float* gamma,
+                                    const float* beta, float eps, float momentum,
+                                    float* running_mean, float* running_var, float* mean,
+                                    float* rstd, float* scale, float* shift, void* workspace,
+                                    pe_stream_t stream) {
+    int32_t rc = bn_check("pe_bn_stats_bf16", M, C);
+    if (rc != PE_OK) return rc;
+    PE_REQUIRE(z && gamma && beta && mean && rstd && scale && shift && workspace, PE_E_INVALID,
+               "pe_bn_stats_bf16: NULL pointer");
+    PE_REQUIRE((running_mean == nullptr) == (running_var == nullptr), PE_E_INVALID,
+               "pe_bn_stats_bf16: give both running buffers or neither");
+    PE_REQUIRE(aligned(z, 16), PE_E_INVALID, "pe_bn_stats_bf16: z not 16-byte aligned");
+    const BnGeom g = bn_geom(M, C);
+    float* partial = static_cast<float*>(workspace);
+    hipStream_t st = as_stream(stream);
+    bn_reduce_kernel<0><<<g.nblk, 256, (size_t)g.rl * 2 * C * sizeof(float), st>>>(
+        static_cast<const uint16_t*>(z), nullptr, nullptr, M, C, g, partial);
+    rc = check_launch("pe_bn_stats_bf16(reduce)");
+    if (rc != PE_OK) return rc;
+    const BnFwdOut o{mean, rstd, scale, shift, running_mean, running_var};
+    const float unbias = M > 1 ? (float)((double)M / (double)(M - 1)) : 1.0f;
+    bn_fwd_finalize_kernel<<<(C + 255) / 256, 256, 0, st>>>(partial, g.nblk, C,
+                                                           (float)(1.0 / (double)M), unbias, gamma,
+                                                           beta, eps, momentum, o);
+    return check_launch("pe_bn_stats_bf16(finalize)");
+}
+
+extern "C" int32_t pe_bn_apply_bf16(const void* z, int64_t M, int32_t C, const float* scale,
+                                    const float* shift, const void* residual, int32_t relu,
+                                    void* y, pe_stream_t stream) {
+    int32_t rc = bn_check("pe_bn_apply_bf16", M, C);
+    if (rc != PE_OK) return rc;
+    PE_REQUIRE(z && scale && shift && y, PE_E_INVALID, "pe_bn_apply_bf16: NULL pointer");
+    PE_REQUIRE(aligned(z, 16) && aligned(y, 16) && aligned(residual, 16) && aligned(scale, 16) &&
+                   aligned(shift, 16),
+               PE_E_INVALID, "pe_bn_apply_bf16: tensors must be 16-byte aligned");
+    const long nchunk = M * (C / 8);
+    bn_apply_kernel<<<ew_grid(nchunk), 256, 0, as_stream(stream)>>>(
+        static_cast<const uint16_t*>(z), nchunk, C / 8, scale, shift,
+        static_cast<const uint16_t*>(residual), relu, static_cast<uint16_t*>(y));
+    return check_launch("pe_bn_apply_bf16");
+}
+
+extern "C" int32_t pe_bn_bwd_bf16(const void* da, const void* a, const void* z, int64_t M,
+                                  int32_t C, const float* gamma, const float* mean,
+                                  const float* rstd, float* dgamma, float* dbeta, void* dz,
+                                  void* dmasked, void* workspace, pe_stream_t stream) {
+    int32_t rc = bn_check("pe_bn_bwd_bf16", M, C);
+    if (rc != PE_OK) return rc;
+    PE_REQUIRE(da && z && gamma && mean && rstd && dgamma && dbeta && dz && workspace,
+               PE_E_INVALID, "pe_bn_bwd_bf16: NULL pointer");
+    PE_REQUIRE(aligned(da, 16) && aligned(a, 16) && aligned(z, 16) && aligned(dz, 16) &&
+                   aligned(dmasked, 16),
+               PE_E_INVALID, "pe_bn_bwd_bf16: tensors must be 16-byte aligned");
+    const BnGeom g = bn_geom(M, C);
+    float* partial = static_cast<float*>(workspace);
+    float* coefA = partial + (size_t)kBnMaxBlocks * 2 * C;
+    float* coefB = coefA + C;
+    float* coefC = coefB + C;
+    hipStream_t st = as_stream(stream);
+    bn_reduce_kernel<1><<<g.nblk, 256, (size_t)g.rl * 2 * C * sizeof(float), st>>>(
+        static_cast<const uint16_t*>(z), static_cast<const uint16_t*>(da),
+        static_cast<const uint16_t*>(a), M, C, g, partial);
+    rc = check_launch("pe_bn_bwd_bf16(reduce)");
+    if (rc != PE_OK) return rc;
+    bn_bwd_finalize_kernel<<<(C + 255) / 256, 256, 0, st>>>(partial, g.nblk, C,
+                                                           (float)(1.0 / (double)M), gamma, mean,
+                                                           rstd, dgamma, dbeta, coefA, coefB, coefC);
+    rc = check_launch("pe_bn_bwd_bf16(finalize)");
+    if (rc != PE_OK) return rc;
+    const long nchunk = M * (C / 8);
+    bn_bwd_apply_kernel<<<ew_grid(nchunk), 256, 0, st>>>(
+        static_cast<const uint16_t*>(da), static_cast<const uint16_t*>(a),
+        static_cast<const uint16_t*>(z), nchunk, C / 8, mean, coefA, coefB, coefC,
+        static_cast<uint16_t*>(dz), static_cast<uint16_t*>(dmasked));
+    return check_launch("pe_bn_bwd_bf16(apply)");
+}

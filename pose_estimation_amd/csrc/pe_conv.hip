@@ -6,13 +6,7 @@
 
 namespace pe {
 
-static void base_params(IgemmParams& p) {
-    p = IgemmParams{};
-    p.cshift = 31;
-    p.cmask = 0x7fffffff;
-    p.osy = p.osx = 1;
-    p.sy = p.sx = 1;
-}
+static void base_params(IgemmParams& p) { igemm_defaults(p); }
 
 // ---------------------------------------------------------------------------------------------
 // uint8 RGB -> normalised bf16, 2x2 space-to-depth, 16 channels per pixel: (ry, rx, c) in the

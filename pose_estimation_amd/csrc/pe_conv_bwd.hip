@@ -1,0 +1,394 @@
+// a4 / a5 backward entry points.
+//
+// Backward-data passes are gather-convs over the output gradient with transposed weights
+// ([Cin][taps][Cout]) and run on the forward engine (pe_igemm.hip): stride-1 convs as one
+// launch, stride-2 convs as up to four input-parity phases with a scattered store, the 4x4/2
+// transposed conv as one 16-tap stride-2 conv.  Backward-weight passes run on pe_wgrad.hip.
+// The rest of the file is the small bandwidth-bound glue of the backward graph: weight
+// transposes, max-pool backward, the float32-NCHW -> bf16-NHWC hand-over of the loss gradient.
+#include "pe_common.h"
+#include "pe_igemm.h"
+#include "pe_wgrad.h"
+
+namespace pe {
+
+// in [A][T][C] bf16 -> out[c][t0 + t][a] with rows of `slots * apitch` elements.
+// 64 x 64 tiles through LDS so both sides move whole 128-byte runs.
+__global__ __launch_bounds__(256) void transpose_w_kernel(const uint16_t* __restrict__ in, int A,
+                                                          int T, int C,
+                                                          uint16_t* __restrict__ out, int slots,
+                                                          int apitch, int t0) {
+    __shared__ uint16_t tile[64][66];
+    const int t = blockIdx.z;
+    const int a0 = blockIdx.y * 64;
+    const int c0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 63;
+    const int ty = threadIdx.x >> 6;
+    for (int r = ty; r < 64; r += 4) {
+        const int a = a0 + r, c = c0 + tx;
+        tile[r][tx] = (a < A && c < C) ? in[((long)a * T + t) * C + c] : (uint16_t)0;
+    }
+    __syncthreads();
+    for (int r = ty; r < 64; r += 4) {
+        const int c = c0 + r, a = a0 + tx;
+        if (c < C && a < A) out[(long)c * slots * apitch + (long)(t0 + t) * apitch + a] = tile[tx][r];
+    }
+}
+
+// Max-pool 3x3/2 pad 1 backward in gather form: an input cell receives the gradient of every
+// window whose FIRST maximum (scan order ky, kx) it is - the same tie rule as an arg-max pool.
+__global__ __launch_bounds__(256) void maxpool3x3s2_bwd_kernel(const uint16_t* __restrict__ x,
+                                                               const uint16_t* __restrict__ dy,
+                                                               int B, int H, int W, int C,
+                                                               uint16_t* __restrict__ dx) {
+    const int Ho = H / 2, Wo = W / 2;
+    const long total = (long)B * H * W * C;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const int c = (int)(e % C);
+        long r = e / C;
+        const int ix = (int)(r % W);
+        r /= W;
+        const int iy = (int)(r % H);
+        const long b = r / H;
+        const float v = bf16_bits_to_float(x[e]);
+        float g = 0.0f;
+        // windows (oy, ox) with oy*2-1 <= iy <= oy*2+1
+        for (int oy = (iy) / 2; oy <= (iy + 1) / 2; ++oy) {
+            if (oy >= Ho) continue;
+            for (int ox = (ix) / 2; ox <= (ix + 1) / 2; ++ox) {
+                if (ox >= Wo) continue;
+                // is (iy, ix) the first maximum of this window?
+                bool first = true;
+                for (int ky = 0; ky < 3 && first; ++ky) {
+                    const int yy = oy * 2 - 1 + ky;
+                    if ((unsigned)yy >= (unsigned)H) continue;
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const int xx = ox * 2 - 1 + kx;
+                        if ((unsigned)xx >= (unsigned)W) continue;
+                        const float u = bf16_bits_to_float(x[((b * H + yy) * W + xx) * (long)C + c]);
+                        const bool before = (yy < iy) || (yy == iy && xx < ix);
+                        if (u > v || (before && u == v)) {
+                            first = false;
+                            break;
+                        }
+                    }
+                }
+                if (first) g += bf16_bits_to_float(dy[((b * Ho + oy) * Wo + ox) * (long)C + c]);
+            }
+        }
+        dx[e] = (uint16_t)float_to_bf16_bits(g);
+    }
+}
+
+// Loss gradient hand-over: float32 [B][K][HW] -> bf16 [B*HW][Kpad] (zero padded) and the bias
+// gradient dbias[k] += sum over pixels.
+__global__ __launch_bounds__(256) void final_grad_prepare_kernel(const float* __restrict__ g,
+                                                                 long npix, int K, int HW,
+                                                                 int Kpad,
+                                                                 uint16_t* __restrict__ out,
+                                                                 float* __restrict__ dbias) {
+    __shared__ float red[32];
+    if (threadIdx.x < 32) red[threadIdx.x] = 0.0f;
+    __syncthreads();
+    const long pix = (long)blockIdx.x * 256 + threadIdx.x;
+    const bool ok = pix < npix;
+    const long b = ok ? pix / HW : 0;
+    const int pl = ok ? (int)(pix - b * HW) : 0;
+    for (int k = 0; k < Kpad; ++k) {
+        float v = 0.0f;
+        if (ok && k < K) v = g[(b * K + k) * HW + pl];
+        if (ok) out[pix * Kpad + k] = (uint16_t)float_to_bf16_bits(v);
+        if (k < K && dbias) {
+            const float s = wave_sum(v);
+            if ((threadIdx.x & 63) == 0) atomicAdd(&red[k], s);
+        }
+    }
+    __syncthreads();
+    if (dbias && threadIdx.x < K) atomicAdd(dbias + threadIdx.x, red[threadIdx.x]);
+}
+
+__global__ __launch_bounds__(256) void mul_f32_kernel(float* __restrict__ a,
+                                                      const float* __restrict__ b, long n) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
+        a[i] *= b[i];
+}
+
+}  // namespace pe
+
+using namespace pe;
+
+extern "C" int32_t pe_conv2d_bwd_data_bf16(const pe_conv_desc* d, const void* dy, const void* w_t,
+                                           const void* residual, void* dx, pe_stream_t stream) {
+    PE_REQUIRE(d != nullptr, PE_E_INVALID, "pe_conv2d_bwd_data_bf16: NULL descriptor");
+    PE_REQUIRE(d->KH > 0 && d->KW > 0 && d->KH * d->KW <= kMaxTaps, PE_E_UNSUPPORTED,
+               "pe_conv2d_bwd_data_bf16: filter %dx%d not supported", d->KH, d->KW);
+    PE_REQUIRE(d->stride == 1 || d->stride == 2, PE_E_UNSUPPORTED,
+               "pe_conv2d_bwd_data_bf16: stride must be 1 or 2");
+    PE_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0 && d->pad >= 0,
+               PE_E_INVALID, "pe_conv2d_bwd_data_bf16: bad sizes");
+    const int s = d->stride;
+    const int Ho = (d->H + 2 * d->pad - d->KH) / s + 1;
+    const int Wo = (d->W + 2 * d->pad - d->KW) / s + 1;
+    PE_REQUIRE(Ho > 0 && Wo > 0, PE_E_INVALID, "pe_conv2d_bwd_data_bf16: empty output");
+    hipStream_t st = as_stream(stream);
+    const int T = d->KH * d->KW;
+
+    // which phases have taps?
+    bool need_zero = false;
+    for (int py = 0; py < s; ++py)
+        for (int px = 0; px < s; ++px) {
+            int cnt = 0;
+            for (int kh = 0; kh < d->KH; ++kh)
+                for (int kw = 0; kw < d->KW; ++kw)
+                    if (((py + d->pad - kh) % s) == 0 && ((px + d->pad - kw) % s) == 0) ++cnt;
+            if (cnt == 0) need_zero = true;
+        }
+    if (need_zero) {
+        PE_REQUIRE(residual == nullptr, PE_E_UNSUPPORTED,
+                   "pe_conv2d_bwd_data_bf16: residual needs every input parity to have a tap");
+        PE_REQUIRE(dx != nullptr, PE_E_INVALID, "pe_conv2d_bwd_data_bf16: NULL dx");
+        const hipError_t e = hipMemsetAsync(dx, 0, (size_t)d->B * d->H * d->W * d->Cin * 2, st);
+        PE_REQUIRE(e == hipSuccess, PE_E_HIP, "pe_conv2d_bwd_data_bf16: memset: %s",
+                   hipGetErrorString(e));
+    }
+    for (int py = 0; py < s; ++py)
+        for (int px = 0; px < s; ++px) {
+            IgemmParams p;
+            igemm_defaults(p);
+            int t = 0;
+            for (int kh = 0; kh < d->KH; ++kh)
+                for (int kw = 0; kw < d->KW; ++kw) {
+                    const int ny = py + d->pad - kh, nx = px + d->pad - kw;
+                    if ((ny % s) != 0 || (nx % s) != 0) continue;
+                    p.tap_dy[t] = (int16_t)(ny / s);
+                    p.tap_dx[t] = (int16_t)(nx / s);
+                    p.tap_slot[t] = (uint8_t)(kh * d->KW + kw);
+                    ++t;
+                }
+            if (t == 0) continue;
+            const int Hp = (d->H - py + s - 1) / s, Wp = (d->W - px + s - 1) / s;
+            if (Hp <= 0 || Wp <= 0) continue;
+            p.x = static_cast<const uint16_t*>(dy);
+            p.w = static_cast<const uint16_t*>(w_t);
+            p.y = dx;
+            p.res = static_cast<const uint16_t*>(residual);
+            p.B = d->B;
+            p.Hi = Ho;
+            p.Wi = Wo;
+            p.Cx = d->Cout;
+            p.Cin = d->Cout;
+            p.Ho = Hp;
+            p.Wo = Wp;
+            p.N = d->Cin;
+            p.T = t;
+            p.wk_row = T * d->Cout;
+            p.OH = d->H;
+            p.OW = d->W;
+            p.osy = p.osx = s;
+            p.ooy = py;
+            p.oox = px;
+            p.ldc = d->Cin;
+            const int32_t rc = igemm_launch(p, st, "pe_conv2d_bwd_data_bf16");
+            if (rc != PE_OK) return rc;
+        }
+    return PE_OK;
+}
+
+extern "C" int32_t pe_deconv4x4s2_bwd_data_bf16(int32_t B, int32_t H, int32_t W, int32_t Cin,
+                                                int32_t Cout, const void* dy, const void* w_t,
+                                                void* dx, pe_stream_t stream) {
+    PE_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, PE_E_INVALID,
+               "pe_deconv4x4s2_bwd_data_bf16: sizes must be positive");
+    IgemmParams p;
+    igemm_defaults(p);
+    int t = 0;
+    for (int py = 0; py < 2; ++py)
+        for (int px = 0; px < 2; ++px)
+            for (int a = 0; a < 2; ++a)
+                for (int b = 0; b < 2; ++b) {
+                    const int dyy = a == 0 ? 0 : (py == 0 ? -1 : 1);
+                    const int dxx = b == 0 ? 0 : (px == 0 ? -1 : 1);
+                    p.tap_dy[t] = (int16_t)(py - 2 * dyy);
+                    p.tap_dx[t] = (int16_t)(px - 2 * dxx);
+                    p.tap_slot[t] = (uint8_t)((2 * py + px) * 4 + 2 * a + b);
+                    ++t;
+                }
+    p.x = static_cast<const uint16_t*>(dy);
+    p.w = static_cast<const uint16_t*>(w_t);
+    p.y = dx;
+    p.B = B;
+    p.Hi = 2 * H;
+    p.Wi = 2 * W;
+    p.Cx = Cout;
+    p.Cin = Cout;
+    p.Ho = H;
+    p.Wo = W;
+    p.sy = p.sx = 2;
+    p.N = Cin;
+    p.T = 16;
+    p.OH = H;
+    p.OW = W;
+    p.ldc = Cin;
+    return igemm_launch(p, as_stream(stream), "pe_deconv4x4s2_bwd_data_bf16");
+}
+
+extern "C" int32_t pe_conv2d_bwd_weight_bf16(const pe_conv_desc* d, const void* x, const void* dy,
+                                             int32_t ldy, float* dw, pe_stream_t stream) {
+    PE_REQUIRE(d != nullptr, PE_E_INVALID, "pe_conv2d_bwd_weight_bf16: NULL descriptor");
+    PE_REQUIRE(d->KH > 0 && d->KW > 0 && d->KH * d->KW <= kMaxTaps, PE_E_UNSUPPORTED,
+               "pe_conv2d_bwd_weight_bf16: filter %dx%d not supported", d->KH, d->KW);
+    PE_REQUIRE(d->stride >= 1 && d->pad >= 0 && d->B > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 &&
+                   d->Cout > 0,
+               PE_E_INVALID, "pe_conv2d_bwd_weight_bf16: bad sizes");
+    const int Ho = (d->H + 2 * d->pad - d->KH) / d->stride + 1;
+    const int Wo = (d->W + 2 * d->pad - d->KW) / d->stride + 1;
+    const int Npad = (d->Cout + 7) / 8 * 8;
+    PE_REQUIRE(ldy >= Npad, PE_E_INVALID,
+               "pe_conv2d_bwd_weight_bf16: dy pitch %d smaller than Cout rounded up to 8", ldy);
+    WgradParams p;
+    wgrad_defaults(p);
+    p.x = static_cast<const uint16_t*>(x);
+    p.dy = static_cast<const uint16_t*>(dy);
+    p.dw = dw;
+    p.B = d->B;
+    p.Hi = d->H;
+    p.Wi = d->W;
+    p.Cx = d->Cin;
+    p.Cin = d->Cin;
+    p.Ho = Ho;
+    p.Wo = Wo;
+    p.sy = p.sx = d->stride;
+    p.N = Npad;
+    p.Nw = d->Cout;
+    p.T = d->KH * d->KW;
+    for (int kh = 0; kh < d->KH; ++kh)
+        for (int kw = 0; kw < d->KW; ++kw) {
+            p.tap_dy[kh * d->KW + kw] = (int16_t)(kh - d->pad);
+            p.tap_dx[kh * d->KW + kw] = (int16_t)(kw - d->pad);
+        }
+    p.OH = Ho;
+    p.OW = Wo;
+    p.ldy = ldy;
+    return wgrad_launch(p, as_stream(stream), "pe_conv2d_bwd_weight_bf16");
+}
+
+extern "C" int32_t pe_deconv4x4s2_bwd_weight_bf16(int32_t B, int32_t H, int32_t W, int32_t Cin,
+                                                  int32_t Cout, const void* x, const void* dy,
+                                                  float* dw_phases, pe_stream_t stream) {
+    PE_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, PE_E_INVALID,
+               "pe_deconv4x4s2_bwd_weight_bf16: sizes must be positive");
+    PE_REQUIRE(dw_phases != nullptr, PE_E_INVALID, "pe_deconv4x4s2_bwd_weight_bf16: NULL dw");
+    for (int py = 0; py < 2; ++py)
+        for (int px = 0; px < 2; ++px) {
+            WgradParams p;
+            wgrad_defaults(p);
+            p.x = static_cast<const uint16_t*>(x);
+            p.dy = static_cast<const uint16_t*>(dy);
+            p.dw = dw_phases + (size_t)(2 * py + px) * Cout * 4 * Cin;
+            p.B = B;
+            p.Hi = H;
+            p.Wi = W;
+            p.Cx = Cin;
+            p.Cin = Cin;
+            p.Ho = H;
+            p.Wo = W;
+            p.N = Cout;
+            p.Nw = Cout;
+            p.T = 4;
+            for (int a = 0; a < 2; ++a)
+                for (int b = 0; b < 2; ++b) {
+                    p.tap_dy[2 * a + b] = (int16_t)(a == 0 ? 0 : (py == 0 ? -1 : 1));
+                    p.tap_dx[2 * a + b] = (int16_t)(b == 0 ? 0 : (px == 0 ? -1 : 1));
+                }
+            p.OH = 2 * H;
+            p.OW = 2 * W;
+            p.osy = p.osx = 2;
+            p.ooy = py;
+            p.oox = px;
+            p.ldy = Cout;
+            const int32_t rc = wgrad_launch(p, as_stream(stream), "pe_deconv4x4s2_bwd_weight_bf16");
+            if (rc != PE_OK) return rc;
+        }
+    return PE_OK;
+}
+
+extern "C" int32_t pe_stem7x7s2_bwd_weight_bf16(int32_t B, int32_t H2, int32_t W2, int32_t Cout,
+                                                const void* x_s2d, const void* dy, float* dw,
+                                                pe_stream_t stream) {
+    PE_REQUIRE(B > 0 && H2 > 0 && W2 > 0 && Cout > 0, PE_E_INVALID,
+               "pe_stem7x7s2_bwd_weight_bf16: sizes must be positive");
+    WgradParams p;
+    wgrad_defaults(p);
+    p.x = static_cast<const uint16_t*>(x_s2d);
+    p.dy = static_cast<const uint16_t*>(dy);
+    p.dw = dw;
+    p.B = B;
+    p.Hi = H2;
+    p.Wi = W2;
+    p.Cx = 16;
+    p.Cin = 64;
+    p.cshift = 4;
+    p.cmask = 15;
+    p.Ho = H2;
+    p.Wo = W2;
+    p.N = Cout;
+    p.Nw = Cout;
+    p.T = 4;
+    for (int r = 0; r < 4; ++r) {
+        p.tap_dy[r] = (int16_t)(r - 2);
+        p.tap_dx[r] = -2;
+    }
+    p.OH = H2;
+    p.OW = W2;
+    p.ldy = Cout;
+    return wgrad_launch(p, as_stream(stream), "pe_stem7x7s2_bwd_weight_bf16");
+}
+
+extern "C" int32_t pe_transpose_weights_bf16(const void* in, int32_t A, int32_t T, int32_t C,
+                                             void* out, int32_t slots, int32_t apitch, int32_t t0,
+                                             pe_stream_t stream) {
+    PE_REQUIRE(in && out, PE_E_INVALID, "pe_transpose_weights_bf16: NULL pointer");
+    PE_REQUIRE(A > 0 && T > 0 && C > 0 && slots >= t0 + T && t0 >= 0 && apitch >= A, PE_E_INVALID,
+               "pe_transpose_weights_bf16: bad sizes");
+    PE_REQUIRE(T <= 65535, PE_E_UNSUPPORTED, "pe_transpose_weights_bf16: too many taps");
+    dim3 grid((C + 63) / 64, (A + 63) / 64, T);
+    transpose_w_kernel<<<grid, 256, 0, as_stream(stream)>>>(
+        static_cast<const uint16_t*>(in), A, T, C, static_cast<uint16_t*>(out), slots, apitch, t0);
+    return check_launch("pe_transpose_weights_bf16");
+}
+
+extern "C" int32_t pe_maxpool3x3s2_bwd_bf16(const void* x, const void* dy, int32_t B, int32_t H,
+                                            int32_t W, int32_t C, void* dx, pe_stream_t stream) {
+    PE_REQUIRE(x && dy && dx, PE_E_INVALID, "pe_maxpool3x3s2_bwd_bf16: NULL pointer");
+    PE_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && H % 2 == 0 && W % 2 == 0, PE_E_UNSUPPORTED,
+               "pe_maxpool3x3s2_bwd_bf16: need even H and W");
+    const long total = (long)B * H * W * C;
+    long blocks = (total + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    maxpool3x3s2_bwd_kernel<<<(unsigned)blocks, 256, 0, as_stream(stream)>>>(
+        static_cast<const uint16_t*>(x), static_cast<const uint16_t*>(dy), B, H, W, C,
+        static_cast<uint16_t*>(dx));
+    return check_launch("pe_maxpool3x3s2_bwd_bf16");
+}
+
+extern "C" int32_t pe_final_grad_prepare_bf16(const float* g_nchw, int32_t B, int32_t K,
+                                              int32_t HW, int32_t Kpad, void* out_nhwc,
+                                              float* dbias, pe_stream_t stream) {
+    PE_REQUIRE(g_nchw && out_nhwc, PE_E_INVALID, "pe_final_grad_prepare_bf16: NULL pointer");
+    PE_REQUIRE(B > 0 && K > 0 && HW > 0 && K <= 32 && Kpad >= K, PE_E_UNSUPPORTED,
+               "pe_final_grad_prepare_bf16: need 0 < K <= 32 and Kpad >= K");
+    const long npix = (long)B * HW;
+    final_grad_prepare_kernel<<<(unsigned)((npix + 255) / 256), 256, 0, as_stream(stream)>>>(
+        g_nchw, npix, K, HW, Kpad, static_cast<uint16_t*>(out_nhwc), dbias);
+    return check_launch("pe_final_grad_prepare_bf16");
+}
+
+extern "C" int32_t pe_mul_f32(float* a, const float* b, int64_t n, pe_stream_t stream) {
+    PE_REQUIRE(n >= 0, PE_E_INVALID, "pe_mul_f32: negative n");
+    if (n == 0) return PE_OK;
+    PE_REQUIRE(a && b, PE_E_INVALID, "pe_mul_f32: NULL pointer");
+    long blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    mul_f32_kernel<<<(unsigned)blocks, 256, 0, as_stream(stream)>>>(a, b, n);
+    return check_launch("pe_mul_f32");
+}

@@ -32,13 +32,25 @@ struct IgemmParams {
     int cshift;             // log2(Cx) when a tap's K run spans several pixels, else 31
     int cmask;              // Cx-1 in that case, else 0x7fffffff
     int T;                  // taps
+    int wk_row;             // weight row length in elements (0 = T*Cin, taps packed densely)
     int OH, OW, osy, osx, ooy, oox;  // output scatter
     int ldc;                // output channels per pixel (bf16 NHWC) / unused for f32 NCHW
     int relu;
     int out_mode;           // 0: bf16 NHWC   1: f32 NCHW [B][N][OH*OW]
     int16_t tap_dy[kMaxTaps];
     int16_t tap_dx[kMaxTaps];
+    uint8_t tap_slot[kMaxTaps];  // position of each tap's Cin-block inside a weight row
 };
+
+// Neutral defaults: unit strides, identity scatter, densely packed taps, single-pixel K runs.
+inline void igemm_defaults(IgemmParams& p) {
+    p = IgemmParams{};
+    p.cshift = 31;
+    p.cmask = 0x7fffffff;
+    p.osy = p.osx = 1;
+    p.sy = p.sx = 1;
+    for (int i = 0; i < kMaxTaps; ++i) p.tap_slot[i] = (uint8_t)i;
+}
 
 // Launches the engine (asynchronous).  Returns PE_OK / PE_E_*.
 int32_t igemm_launch(const IgemmParams& p, hipStream_t st, const char* what);

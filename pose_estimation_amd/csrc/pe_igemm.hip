@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
     }
     const int kc = p.Cin / BK;          // K steps per tap
     const int KT = p.T * kc;            // K steps in total
-    const long ktot = (long)p.T * p.Cin;  // weight row length
+    const long ktot = p.wk_row;         // weight row length
 
     uint4 xr[4], wr[WROWS];
     int tap = 0, cstep = 0;  // position of the NEXT tile to load
@@ -88,6 +88,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
         const int dy = p.tap_dy[tap];
         const int dx = p.tap_dx[tap];
         const int coff = cstep * BK + cc * 8;
+        const long wk = (long)p.tap_slot[tap] * p.Cin + coff;  // K offset inside a weight row
         const int xextra = coff >> p.cshift;
         const int ch = coff & p.cmask;
 #pragma unroll
@@ -101,7 +102,7 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
 #pragma unroll
         for (int i = 0; i < WROWS; ++i) {
             const int n = n0 + r0 + 32 * i;
-            const long off = (long)n * ktot + (long)kt * BK + cc * 8;
+            const long off = (long)n * ktot + wk;
             wr[i] = (n < p.N) ? *reinterpret_cast<const uint4*>(p.w + off) : make_uint4(0, 0, 0, 0);
         }
         if (++cstep == kc) {
@@ -300,7 +301,9 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
     }
 }
 
-int32_t igemm_launch(const IgemmParams& p, hipStream_t st, const char* what) {
+int32_t igemm_launch(const IgemmParams& pin, hipStream_t st, const char* what) {
+    IgemmParams p = pin;
+    if (p.wk_row == 0) p.wk_row = p.T * p.Cin;
     PE_REQUIRE(p.x && p.w && p.y, PE_E_INVALID, "%s: NULL tensor pointer", what);
     PE_REQUIRE(p.B > 0 && p.Hi > 0 && p.Wi > 0 && p.Ho > 0 && p.Wo > 0 && p.N > 0, PE_E_INVALID,
                "%s: sizes must be positive", what);

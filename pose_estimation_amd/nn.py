@@ -166,3 +166,173 @@ def maxpool3x3s2(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.T
     with torch.cuda.device(x.device):
         check(lib().pe_maxpool3x3s2_fwd_bf16(x.data_ptr(), B, H, W, C, out.data_ptr(), _stream(x)))
     return out
+
+
+# --------------------------------------------------------------------------- backward
+def transpose_weights(w: torch.Tensor, out: torch.Tensor, t0: int = 0) -> torch.Tensor:
+    """out[c, t0 + t, a] = w[a, t, c]; w is any packed weight viewed as [A,T,C] bf16 and out a
+    contiguous bf16 [C, slots, apitch] with apitch >= A (columns past A are left untouched)."""
+    _need_gpu(w, out)
+    A, T, C = w.shape
+    C2, slots, apitch = out.shape
+    if C2 != C or w.dtype != BF16 or out.dtype != BF16 or not (w.is_contiguous() and out.is_contiguous()):
+        raise ValueError("transpose_weights: w [A,T,C], out [C,slots,apitch], contiguous bf16")
+    with torch.cuda.device(w.device):
+        check(lib().pe_transpose_weights_bf16(w.data_ptr(), A, T, C, out.data_ptr(), slots, apitch,
+                                              t0, _stream(w)))
+    return out
+
+
+def conv2d_bwd_data(dy: torch.Tensor, w_t: torch.Tensor, in_hw, k: int, stride: int, pad: int,
+                    residual: Optional[torch.Tensor] = None,
+                    out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """dx [B,H,W,Cin] of a k x k conv from dy [B,Ho,Wo,Cout] and w_t [Cin, k*k, Cout]."""
+    _check_act(dy, "dy")
+    B, Ho, Wo, Cout = dy.shape
+    Cin = w_t.shape[0]
+    H, W = in_hw
+    if tuple(w_t.shape) != (Cin, k * k, Cout) or w_t.dtype != BF16:
+        raise ValueError("w_t must be bfloat16 [Cin, k*k, Cout]")
+    if out is None:
+        out = torch.empty((B, H, W, Cin), dtype=BF16, device=dy.device)
+    d = ConvDesc(B, H, W, Cin, Cout, k, k, stride, pad, 0, 0)
+    with torch.cuda.device(dy.device):
+        check(lib().pe_conv2d_bwd_data_bf16(ctypes.addressof(d), dy.data_ptr(), w_t.data_ptr(),
+                                            _ptr(residual), out.data_ptr(), _stream(dy)))
+    return out
+
+
+def deconv4x4s2_bwd_data(dy: torch.Tensor, w_t: torch.Tensor,
+                         out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """dx [B,H,W,Cin] from dy [B,2H,2W,Cout] and w_t [Cin,16,Cout]."""
+    _check_act(dy, "dy")
+    B, H2, W2, Cout = dy.shape
+    Cin = w_t.shape[0]
+    if out is None:
+        out = torch.empty((B, H2 // 2, W2 // 2, Cin), dtype=BF16, device=dy.device)
+    with torch.cuda.device(dy.device):
+        check(lib().pe_deconv4x4s2_bwd_data_bf16(B, H2 // 2, W2 // 2, Cin, Cout, dy.data_ptr(),
+                                                 w_t.data_ptr(), out.data_ptr(), _stream(dy)))
+    return out
+
+
+def conv2d_bwd_weight(x: torch.Tensor, dy: torch.Tensor, dw: torch.Tensor, k: int, stride: int,
+                      pad: int, cout: Optional[int] = None) -> None:
+    """dw (float32 [Cout,k,k,Cin], pre-zeroed) += weight gradient.  dy may be zero-padded to more
+    channels than `cout`."""
+    _check_act(x)
+    _check_act(dy, "dy")
+    B, H, W, Cin = x.shape
+    ldy = dy.shape[3]
+    cout = ldy if cout is None else cout
+    if dw.dtype != torch.float32 or dw.numel() != cout * k * k * Cin or not dw.is_contiguous():
+        raise ValueError("dw must be contiguous float32 [Cout,k,k,Cin]")
+    d = ConvDesc(B, H, W, Cin, cout, k, k, stride, pad, 0, 0)
+    with torch.cuda.device(x.device):
+        check(lib().pe_conv2d_bwd_weight_bf16(ctypes.addressof(d), x.data_ptr(), dy.data_ptr(), ldy,
+                                              dw.data_ptr(), _stream(x)))
+
+
+def deconv4x4s2_bwd_weight(x: torch.Tensor, dy: torch.Tensor, dw: torch.Tensor) -> None:
+    _check_act(x)
+    _check_act(dy, "dy")
+    B, H, W, Cin = x.shape
+    Cout = dy.shape[3]
+    if dw.dtype != torch.float32 or dw.numel() != 16 * Cout * Cin:
+        raise ValueError("dw must be float32 [4,Cout,4,Cin]")
+    with torch.cuda.device(x.device):
+        check(lib().pe_deconv4x4s2_bwd_weight_bf16(B, H, W, Cin, Cout, x.data_ptr(), dy.data_ptr(),
+                                                   dw.data_ptr(), _stream(x)))
+
+
+def stem7x7s2_bwd_weight(x_s2d: torch.Tensor, dy: torch.Tensor, dw: torch.Tensor) -> None:
+    _check_act(x_s2d, "x_s2d")
+    _check_act(dy, "dy")
+    B, H2, W2, _ = x_s2d.shape
+    Cout = dy.shape[3]
+    with torch.cuda.device(x_s2d.device):
+        check(lib().pe_stem7x7s2_bwd_weight_bf16(B, H2, W2, Cout, x_s2d.data_ptr(), dy.data_ptr(),
+                                                 dw.data_ptr(), _stream(x_s2d)))
+
+
+def maxpool3x3s2_bwd(x: torch.Tensor, dy: torch.Tensor,
+                     out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _check_act(x)
+    _check_act(dy, "dy")
+    B, H, W, C = x.shape
+    if out is None:
+        out = torch.empty_like(x)
+    with torch.cuda.device(x.device):
+        check(lib().pe_maxpool3x3s2_bwd_bf16(x.data_ptr(), dy.data_ptr(), B, H, W, C,
+                                             out.data_ptr(), _stream(x)))
+    return out
+
+
+def final_grad_prepare(g_nchw: torch.Tensor, kpad: int, dbias: Optional[torch.Tensor] = None,
+                       out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """float32 [B,K,H,W] -> bf16 [B,H,W,kpad] zero padded; dbias[K] (pre-zeroed) += pixel sums."""
+    _need_gpu(g_nchw, dbias)
+    B, K, H, W = g_nchw.shape
+    if out is None:
+        out = torch.empty((B, H, W, kpad), dtype=BF16, device=g_nchw.device)
+    with torch.cuda.device(g_nchw.device):
+        check(lib().pe_final_grad_prepare_bf16(g_nchw.data_ptr(), B, K, H * W, kpad, out.data_ptr(),
+                                               _ptr(dbias), _stream(g_nchw)))
+    return out
+
+
+def mul_(a: torch.Tensor, b: torch.Tensor) -> None:
+    _need_gpu(a, b)
+    with torch.cuda.device(a.device):
+        check(lib().pe_mul_f32(a.data_ptr(), b.data_ptr(), a.numel(), _stream(a)))
+
+
+# --------------------------------------------------------------------------- batch norm
+def bn_workspace(M: int, C: int, device) -> torch.Tensor:
+    return torch.empty(lib().pe_bn_workspace_bytes(M, C), dtype=torch.uint8, device=device)
+
+
+def bn_stats(z: torch.Tensor, gamma, beta, eps: float, momentum: float, running_mean,
+             running_var, ws: torch.Tensor, out=None):
+    """Batch statistics of z [B,H,W,C] -> (mean, rstd, scale, shift), each float32 [C]."""
+    _check_act(z, "z")
+    C = z.shape[3]
+    M = z.numel() // C
+    if out is None:
+        out = torch.empty((4, C), dtype=torch.float32, device=z.device)
+    with torch.cuda.device(z.device):
+        check(lib().pe_bn_stats_bf16(z.data_ptr(), M, C, gamma.data_ptr(), beta.data_ptr(), eps,
+                                     momentum, _ptr(running_mean), _ptr(running_var),
+                                     out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(),
+                                     out[3].data_ptr(), ws.data_ptr(), _stream(z)))
+    return out[0], out[1], out[2], out[3]
+
+
+def bn_apply(z: torch.Tensor, scale, shift, residual=None, relu: bool = True,
+             out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _check_act(z, "z")
+    C = z.shape[3]
+    M = z.numel() // C
+    if out is None:
+        out = torch.empty_like(z)
+    with torch.cuda.device(z.device):
+        check(lib().pe_bn_apply_bf16(z.data_ptr(), M, C, scale.data_ptr(), shift.data_ptr(),
+                                     _ptr(residual), int(relu), out.data_ptr(), _stream(z)))
+    return out
+
+
+def bn_bwd(da: torch.Tensor, a: Optional[torch.Tensor], z: torch.Tensor, gamma, mean, rstd,
+           dgamma, dbeta, ws: torch.Tensor, want_masked: bool = False, dz=None):
+    """Returns (dz, g) where g = da masked by the ReLU (None unless want_masked)."""
+    _check_act(da, "da")
+    C = z.shape[3]
+    M = z.numel() // C
+    if dz is None:
+        dz = torch.empty_like(z)
+    g = torch.empty_like(z) if want_masked else None
+    with torch.cuda.device(z.device):
+        check(lib().pe_bn_bwd_bf16(da.data_ptr(), _ptr(a), z.data_ptr(), M, C, gamma.data_ptr(),
+                                   mean.data_ptr(), rstd.data_ptr(), dgamma.data_ptr(),
+                                   dbeta.data_ptr(), dz.data_ptr(), _ptr(g), ws.data_ptr(),
+                                   _stream(z)))
+    return dz, g
