@@ -238,8 +238,69 @@ class Infer(Workload):
                 "sample": f"torch-CPU float32 oracle forward, batch 8, median of 3 ({med:.2f} s)"}
 
 
+class Train(Workload):
+    """BASELINE configs[3]: full training step (forward with batch statistics, fused target
+    render + masked MSE, backward, gradient all-reduce when N > 1, fused Adam), batch 64 per GPU."""
+    name = "resnet50_pose_train_256x192_b64_bf16"
+    batch = 64
+    dtype = "bf16"
+    bound = "mfma"
+    kernel = "igemm_kernel + wgrad_kernel (all launches of one step)"
+    peak = 2500.0
+    sharding = "data parallel: batch per rank, bucketed gradient all-reduce (RCCL) behind backward"
+
+    def setup(self, device):
+        import torch.distributed as dist
+
+        from pose_estimation_amd import flops, model
+        from pose_estimation_amd.training import TrainablePoseResNet
+
+        self.net = TrainablePoseResNet(device)
+        self.net.load_state(model.init_state(self.net.specs, seed=3))
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            self.net.enable_data_parallel(32 << 20)
+        macs, _, _ = flops.forward_macs(256, 192)
+        self.flops_per_step = 3 * 2.0 * macs * self.batch   # backward = 2 x forward
+        rank = dist.get_rank() if dist.is_initialized() else 0
+        self.imgs = torch.from_numpy(synthetic.images_u8(self.batch, 256, 192, seed=1 + rank)).to(device)
+        self.joints = torch.from_numpy(synthetic.joints(self.batch, K_JOINTS, 256, 192,
+                                                        seed=2 + rank)).to(device)
+        self.mask = torch.from_numpy(synthetic.ignore_mask(self.batch, H, W, seed=4 + rank)).to(device)
+
+    def step(self, i):
+        self.net.train_step(self.imgs, self.joints, self.mask, lr=1e-3)
+
+    def roofline(self, kern_ms):
+        ach = self.flops_per_step / (kern_ms * 1e-3) / 1e12
+        return {"bound": "mfma", "kernel": self.kernel, "achieved": ach, "peak": self.peak,
+                "unit": "TFLOP/s", "frac": ach / self.peak,
+                "flops_per_step": self.flops_per_step, "step_ms": kern_ms, "traffic": None}
+
+    def cpu_baseline(self):
+        import oracle
+        from oracle import torch_oracle as to
+        from pose_estimation_amd import model
+        from pose_estimation_amd import nn as pnn
+
+        specs = model.resnet50_pose_specs()
+        state = model.init_state(specs, seed=3)
+        B = 8
+        img = synthetic.images_u8(B, 256, 192, seed=1)
+        j = synthetic.joints(B, K_JOINTS, 256, 192, seed=2)
+        m = synthetic.ignore_mask(B, H, W, seed=4)
+        t0 = time.perf_counter()
+        t, w = oracle.render_targets(j, H, W, 4.0, 2.0, 6)
+        to.pose_resnet_train_reference(specs, state, img, t, w, m, pnn.IMAGENET_MEAN,
+                                       pnn.IMAGENET_STD)
+        dt = time.perf_counter() - t0
+        return {"value": B / dt, "unit": "images/s", "cores": torch.get_num_threads(),
+                "kind": "port",
+                "sample": f"torch-CPU autograd oracle (render + loss + backward, no optimizer), "
+                          f"batch {B}, one run ({dt:.1f} s)"}
+
+
 WORKLOADS = {"decode": Decode, "render": Render, "mse": Mse, "mse_fused": MseFused, "adam": Adam,
-             "infer": Infer}
+             "infer": Infer, "train": Train}
 
 
 def main() -> None:
@@ -258,13 +319,19 @@ def main() -> None:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback for the measured path)")
-    device = torch.device("cuda", local_rank)
+    # PE_REHEARSE_ON_ONE_GPU=1: every rank uses cuda:0 and the collectives go through gloo, so
+    # the N > 1 code path can be rehearsed on a one-GPU box (RCCL refuses two ranks per device).
+    rehearse = os.environ.get("PE_REHEARSE_ON_ONE_GPU") == "1"
+    device = torch.device("cuda", 0 if rehearse else local_rank)
     torch.cuda.set_device(device)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=device)
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
 
     wl = WORKLOADS[args.workload]()
     wl.setup(device)
@@ -318,7 +385,8 @@ def main() -> None:
             "dtype": wl.dtype,
             "data": "synthetic",
             "config": {"workload": wl.name, "batch_per_gpu": wl.batch, "joints": K_JOINTS,
-                       "heatmap": [H, W], "sharding": "batch, no collective"},
+                       "heatmap": [H, W],
+                       "sharding": getattr(wl, "sharding", "batch, no collective")},
             "roofline": roof,
         }
         # HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE,

@@ -134,3 +134,130 @@ def pose_resnet_forward(specs, state, img_u8: np.ndarray, mean, std, bn_eps: flo
     sc, sh = fold(final)
     y = conv2d(x, bf16r(state[final.name + ".weight"]), sc, sh, acc64=acc64)
     return y.permute(0, 3, 1, 2).contiguous()
+
+
+# ----------------------------------------------------------------------------------------------
+# Training step: forward with batch statistics, masked MSE against rendered targets, autograd.
+# ----------------------------------------------------------------------------------------------
+class _RoundBoth(torch.autograd.Function):
+    """bf16 rounding of a value in forward and of its gradient in backward: the points where
+    the kernels store an activation / an activation gradient in bf16."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return bf16r(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return bf16r(g)
+
+
+class _RoundFwd(torch.autograd.Function):
+    """bf16 rounding in forward only (weights: the bf16 working copy feeds the kernels, the
+    float32 weight gradient is not rounded)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return bf16r(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+def bottleneck_train_reference(b, state, x_nhwc, dout_nhwc, bn_eps: float = 1e-5):
+    """Forward (batch statistics) + autograd backward of ONE bottleneck block on the CPU with
+    bf16 rounding at the kernels' storage points.  x, dout: float32 NHWC holding bf16 values.
+    Returns (out NHWC, dx NHWC, {name: grad in framework layout})."""
+    rb, rw = _RoundBoth.apply, _RoundFwd.apply
+    P = {}
+    for c in (b.c1, b.c2, b.c3) + ((b.down,) if b.down else ()):
+        for nm in (".weight", ".bn.gamma", ".bn.beta"):
+            P[c.name + nm] = state[c.name + nm].clone().requires_grad_(True)
+
+    def bn(c, z, residual=None, relu=True):
+        y = F.batch_norm(z, None, None, P[c.name + ".bn.gamma"], P[c.name + ".bn.beta"],
+                         training=True, momentum=0.0, eps=bn_eps)
+        if residual is not None:
+            y = y + residual
+        return rb(torch.relu(y) if relu else y)
+
+    def conv(c, t):
+        return rb(F.conv2d(t, rw(P[c.name + ".weight"]), None, stride=c.stride, padding=c.pad))
+
+    x = _nchw(x_nhwc).requires_grad_(True)
+    o = bn(b.c1, conv(b.c1, x))
+    o = bn(b.c2, conv(b.c2, o))
+    z3 = conv(b.c3, o)
+    idn = bn(b.down, conv(b.down, x), relu=False) if b.down else x
+    out = bn(b.c3, z3, residual=idn, relu=True)
+    out.backward(_nchw(dout_nhwc))
+    return _nhwc(out.detach()), _nhwc(x.grad), {k: p.grad for k, p in P.items()}
+
+
+def deconv_train_reference(d, state, x_nhwc, da_nhwc, bn_eps: float = 1e-5):
+    """Same for one ConvTranspose(4x4, s2, p1) + BN + ReLU layer."""
+    rb, rw = _RoundBoth.apply, _RoundFwd.apply
+    P = {d.name + nm: state[d.name + nm].clone().requires_grad_(True)
+         for nm in (".weight", ".bn.gamma", ".bn.beta")}
+    x = _nchw(x_nhwc).requires_grad_(True)
+    z = rb(F.conv_transpose2d(x, rw(P[d.name + ".weight"]), None, stride=2, padding=1))
+    y = F.batch_norm(z, None, None, P[d.name + ".bn.gamma"], P[d.name + ".bn.beta"],
+                     training=True, momentum=0.0, eps=bn_eps)
+    a = rb(torch.relu(y))
+    a.backward(_nchw(da_nhwc))
+    return _nhwc(a.detach()), _nhwc(x.grad), {k: p.grad for k, p in P.items()}
+
+
+def pose_resnet_train_reference(specs, state, img_u8, targets, weights, mask, mean, std,
+                                bn_eps: float = 1e-5, round_bf16: bool = True):
+    """One forward/backward of the training graph on the CPU with torch autograd.
+
+    targets [B,K,H,W], weights [B,K], mask [B,H,W] or None: as produced by the NumPy oracle
+    (render_targets).  Loss = 0.5/(BKHW) * sum m (w (p - t))^2.  With round_bf16 the graph rounds
+    to bf16 where the kernels do (weights, every stored activation and activation gradient);
+    without it the graph is plain float32.  Returns (loss, heatmaps, {name: grad}) with grads in
+    framework layouts for every weight / gamma / beta / bias.
+    """
+    stem, blocks, deconvs, final = specs
+    rb = _RoundBoth.apply if round_bf16 else (lambda t: t)
+    rw = _RoundFwd.apply if round_bf16 else (lambda t: t)
+    P = {}
+    for k, v in state.items():
+        if k.endswith(".bn.mean") or k.endswith(".bn.var"):
+            continue
+        P[k] = v.clone().double().float().requires_grad_(True)
+
+    def bn(c, z, residual=None, relu=True):
+        y = F.batch_norm(z, None, None, P[c.name + ".bn.gamma"], P[c.name + ".bn.beta"],
+                         training=True, momentum=0.0, eps=bn_eps)
+        if residual is not None:
+            y = y + residual
+        if relu:
+            y = torch.relu(y)
+        return rb(y)
+
+    def conv(c, x):
+        return rb(F.conv2d(x, rw(P[c.name + ".weight"]), None, stride=c.stride, padding=c.pad))
+
+    x = torch.from_numpy(preprocess_u8(img_u8, mean, std)).permute(0, 3, 1, 2).contiguous()
+    x = bn(stem, conv(stem, x))
+    x = F.max_pool2d(x, 3, 2, 1)
+    for b in blocks:
+        o = bn(b.c1, conv(b.c1, x))
+        o = bn(b.c2, conv(b.c2, o))
+        z3 = conv(b.c3, o)
+        idn = bn(b.down, conv(b.down, x), relu=False) if b.down else x
+        x = bn(b.c3, z3, residual=idn, relu=True)
+    for d in deconvs:
+        z = rb(F.conv_transpose2d(x, rw(P[d.name + ".weight"]), None, stride=2, padding=1))
+        x = bn(d, z)
+    hm = F.conv2d(x, rw(P[final.name + ".weight"]), P[final.name + ".bias"])
+    t = torch.as_tensor(targets)
+    w = torch.as_tensor(weights)[:, :, None, None]
+    e = (w * (hm - t)) ** 2
+    if mask is not None:
+        e = e * torch.as_tensor(mask).bool()[:, None].float()
+    loss = 0.5 * e.mean()
+    loss.backward()
+    return loss.item(), hm.detach(), {k: p.grad for k, p in P.items()}

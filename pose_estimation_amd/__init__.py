@@ -17,4 +17,7 @@ from .ops import (  # noqa: F401
     sgd_step,
 )
 
+from .config import parse_config  # noqa: F401
+from .trainer import Trainer  # noqa: F401
+
 __version__ = "0.1.0"

@@ -1,0 +1,91 @@
+"""Configuration in the reference's shape: a YAML file (or dict) with three sections,
+`data_config`, `train_config`, `model_config`, each exposed as an object with attributes
+(`parse_config('config.yaml')` at test.ipynb:381-386; keys at test.ipynb:962-974, 995-1014).
+
+The reference's own config.yaml is absent; the defaults below are the values its notebook
+prints, plus the model keys this build needs.
+"""
+from __future__ import annotations
+
+import copy
+from typing import Any, Dict, Union
+
+import yaml
+
+
+class Section:
+    """Attribute view of one config section (the reference's objects expose __dict__)."""
+
+    def __init__(self, d: Dict[str, Any]):
+        self.__dict__.update(copy.deepcopy(d))
+
+    def get(self, key: str, default=None):
+        return self.__dict__.get(key, default)
+
+    def __repr__(self) -> str:
+        return f"Section({self.__dict__!r})"
+
+
+DEFAULTS: Dict[str, Dict[str, Any]] = {
+    "data_config": {
+        "synthetic": True,          # the reference's TFRecords are private; batches are synthetic
+        "seed": 0,
+    },
+    "train_config": {               # test.ipynb:995-1014
+        "batch_size": 2,
+        "is_training": True,
+        "learning_rate": 0.001,
+        "learning_rate_decay": {"decay_rate": 0.95, "decay_steps": 10000},
+        "optimizer": {"name": "adam",
+                      "params": {"beta1": 0.9, "beta2": 0.999, "epsilon": "1e-8"}},
+        "preprocess": {"image_resize": [256, 192]},
+        "model_dir": "./models",
+        "num_epochs": 0,
+        "train_keypoints": None,
+    },
+    "model_config": {
+        "backbone": "resnet50",
+        "num_joints": 17,
+        "layers": [3, 4, 6, 3],
+        "head_channels": 256,
+        "heatmap_stride": 4,
+        "sigma": 2.0,
+        "bn_momentum": 0.1,
+        "bucket_mb": 32,
+    },
+}
+
+
+def _merge(base: Dict[str, Any], over: Dict[str, Any]) -> Dict[str, Any]:
+    out = copy.deepcopy(base)
+    for k, v in (over or {}).items():
+        if isinstance(v, dict) and isinstance(out.get(k), dict):
+            out[k] = _merge(out[k], v)
+        else:
+            out[k] = copy.deepcopy(v)
+    return out
+
+
+def parse_config(source: Union[str, Dict[str, Any], None] = None) -> Dict[str, Section]:
+    """YAML path or dict -> {'data_config', 'train_config', 'model_config'} of Section objects.
+    Unknown keys are kept; missing ones take the defaults."""
+    if source is None:
+        raw: Dict[str, Any] = {}
+    elif isinstance(source, dict):
+        raw = source
+    else:
+        with open(source) as f:
+            raw = yaml.safe_load(f) or {}
+    unknown = set(raw) - set(DEFAULTS)
+    if unknown:
+        raise KeyError(f"unknown config sections: {sorted(unknown)}")
+    return {name: Section(_merge(DEFAULTS[name], raw.get(name) or {})) for name in DEFAULTS}
+
+
+def learning_rate_at(train_cfg: Section, step: int) -> float:
+    """Exponential decay lr * rate^(step/steps) (continuous, as tf.train.exponential_decay)."""
+    lr = float(train_cfg.learning_rate)
+    dec = train_cfg.get("learning_rate_decay")
+    if dec:
+        lr *= float(dec["decay_rate"]) ** (step / float(dec["decay_steps"]))
+    return lr

@@ -25,9 +25,10 @@ static BnGeom bn_geom(long M, int C) {
     BnGeom g;
     g.cg = C / 8;
     g.rl = 256 / g.cg;
+    // at least 16 rows per walking thread: fewer partials for the second stage to fold
     long rows = (M + kBnMaxBlocks - 1) / kBnMaxBlocks;
     rows = (rows + g.rl - 1) / g.rl * g.rl;
-    if (rows < (long)g.rl * 4) rows = (long)g.rl * 4;
+    if (rows < (long)g.rl * 16) rows = (long)g.rl * 16;
     g.rows_blk = (int)rows;
     g.nblk = (int)((M + rows - 1) / rows);
     return g;
@@ -109,6 +110,38 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const uint16_t* __restri
     }
 }
 
+// Second reduction stage.  A workgroup folds the per-block partials of 8 channels: thread
+// (slice, ch) adds blocks slice, slice+32, ... in order, then the 32 slices are added in order
+// by the threads of slice 0, which return their channel (every other thread returns -1).
+// Launch with C/8 workgroups of 256 threads.
+constexpr int kFoldCh = 8;
+constexpr int kFoldSlices = 32;
+__device__ __forceinline__ int fold_partials(const float* __restrict__ partial, int nblk, int C,
+                                             float& s1, float& s2) {
+    __shared__ float red[2][kFoldSlices][kFoldCh + 1];
+    const int ch = threadIdx.x & (kFoldCh - 1);
+    const int slice = threadIdx.x / kFoldCh;
+    const int c = blockIdx.x * kFoldCh + ch;
+    float a1 = 0.0f, a2 = 0.0f;
+    if (c < C) {
+        for (int b = slice; b < nblk; b += kFoldSlices) {
+            a1 += partial[(long)b * 2 * C + c];
+            a2 += partial[(long)b * 2 * C + C + c];
+        }
+    }
+    red[0][slice][ch] = a1;
+    red[1][slice][ch] = a2;
+    __syncthreads();
+    if (slice != 0 || c >= C) return -1;
+    s1 = 0.0f;
+    s2 = 0.0f;
+    for (int s = 0; s < kFoldSlices; ++s) {
+        s1 += red[0][s][ch];
+        s2 += red[1][s][ch];
+    }
+    return c;
+}
+
 struct BnFwdOut {
     float *mean, *rstd, *scale, *shift, *running_mean, *running_var;
 };
@@ -118,12 +151,9 @@ __global__ __launch_bounds__(256) void bn_fwd_finalize_kernel(const float* __res
                                                               float unbias, const float* gamma,
                                                               const float* beta, float eps,
                                                               float momentum, BnFwdOut o) {
-    for (int c = blockIdx.x * 256 + threadIdx.x; c < C; c += gridDim.x * 256) {
-        float s1 = 0.0f, s2 = 0.0f;
-        for (int b = 0; b < nblk; ++b) {
-            s1 += partial[(long)b * 2 * C + c];
-            s2 += partial[(long)b * 2 * C + C + c];
-        }
+    float s1, s2;
+    const int c = fold_partials(partial, nblk, C, s1, s2);
+    if (c >= 0) {
         const float mean = s1 * inv_m;
         float var = s2 * inv_m - mean * mean;
         var = fmaxf(var, 0.0f);
@@ -148,12 +178,9 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
                                                               const float* rstd, float* dgamma,
                                                               float* dbeta, float* coefA,
                                                               float* coefB, float* coefC) {
-    for (int c = blockIdx.x * 256 + threadIdx.x; c < C; c += gridDim.x * 256) {
-        float s1 = 0.0f, s2 = 0.0f;
-        for (int b = 0; b < nblk; ++b) {
-            s1 += partial[(long)b * 2 * C + c];
-            s2 += partial[(long)b * 2 * C + C + c];
-        }
+    float s1, s2;
+    const int c = fold_partials(partial, nblk, C, s1, s2);
+    if (c >= 0) {
         const float dg = (s2 - mean[c] * s1) * rstd[c];
         dgamma[c] = dg;
         dbeta[c] = s1;
@@ -266,7 +293,7 @@ extern "C" int32_t pe_bn_stats_bf16(const void* z, int64_t M, int32_t C, const f
     if (rc != PE_OK) return rc;
     const BnFwdOut o{mean, rstd, scale, shift, running_mean, running_var};
     const float unbias = M > 1 ? (float)((double)M / (double)(M - 1)) : 1.0f;
-    bn_fwd_finalize_kernel<<<(C + 255) / 256, 256, 0, st>>>(partial, g.nblk, C,
+    bn_fwd_finalize_kernel<<<(C + kFoldCh - 1) / kFoldCh, 256, 0, st>>>(partial, g.nblk, C,
                                                            (float)(1.0 / (double)M), unbias, gamma,
                                                            beta, eps, momentum, o);
     return check_launch("pe_bn_stats_bf16(finalize)");
@@ -310,7 +337,7 @@ extern "C" int32_t pe_bn_bwd_bf16(const void* da, const void* a, const void* z, 
         static_cast<const uint16_t*>(a), M, C, g, partial);
     rc = check_launch("pe_bn_bwd_bf16(reduce)");
     if (rc != PE_OK) return rc;
-    bn_bwd_finalize_kernel<<<(C + 255) / 256, 256, 0, st>>>(partial, g.nblk, C,
+    bn_bwd_finalize_kernel<<<(C + kFoldCh - 1) / kFoldCh, 256, 0, st>>>(partial, g.nblk, C,
                                                            (float)(1.0 / (double)M), gamma, mean,
                                                            rstd, dgamma, dbeta, coefA, coefB, coefC);
     rc = check_launch("pe_bn_bwd_bf16(finalize)");

@@ -41,42 +41,72 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_bwd_kernel(const uint16_t* _
                                                                const uint16_t* __restrict__ dy,
                                                                int B, int H, int W, int C,
                                                                uint16_t* __restrict__ dx) {
-    const int Ho = H / 2, Wo = W / 2;
-    const long total = (long)B * H * W * C;
+    // one thread per 8 channels of one input cell, 16-byte accesses
+    const int Ho = H / 2, Wo = W / 2, C8 = C / 8;
+    const long total = (long)B * H * W * C8;
     for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
-        const int c = (int)(e % C);
-        long r = e / C;
+        const int c8 = (int)(e % C8);
+        long r = e / C8;
         const int ix = (int)(r % W);
         r /= W;
         const int iy = (int)(r % H);
         const long b = r / H;
-        const float v = bf16_bits_to_float(x[e]);
-        float g = 0.0f;
+        float v[8], g[8];
+        {
+            const uint4 xv = *reinterpret_cast<const uint4*>(x + e * 8);
+            const uint32_t u[4] = {xv.x, xv.y, xv.z, xv.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                v[2 * i] = bf16_bits_to_float(u[i] & 0xffffu);
+                v[2 * i + 1] = bf16_bits_to_float(u[i] >> 16);
+                g[2 * i] = g[2 * i + 1] = 0.0f;
+            }
+        }
         // windows (oy, ox) with oy*2-1 <= iy <= oy*2+1
-        for (int oy = (iy) / 2; oy <= (iy + 1) / 2; ++oy) {
+        for (int oy = iy / 2; oy <= (iy + 1) / 2; ++oy) {
             if (oy >= Ho) continue;
-            for (int ox = (ix) / 2; ox <= (ix + 1) / 2; ++ox) {
+            for (int ox = ix / 2; ox <= (ix + 1) / 2; ++ox) {
                 if (ox >= Wo) continue;
-                // is (iy, ix) the first maximum of this window?
-                bool first = true;
-                for (int ky = 0; ky < 3 && first; ++ky) {
+                // per channel: is (iy, ix) the first maximum of this window?
+                bool first[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) first[i] = true;
+                for (int ky = 0; ky < 3; ++ky) {
                     const int yy = oy * 2 - 1 + ky;
                     if ((unsigned)yy >= (unsigned)H) continue;
                     for (int kx = 0; kx < 3; ++kx) {
                         const int xx = ox * 2 - 1 + kx;
                         if ((unsigned)xx >= (unsigned)W) continue;
-                        const float u = bf16_bits_to_float(x[((b * H + yy) * W + xx) * (long)C + c]);
                         const bool before = (yy < iy) || (yy == iy && xx < ix);
-                        if (u > v || (before && u == v)) {
-                            first = false;
-                            break;
+                        const uint4 nv = *reinterpret_cast<const uint4*>(
+                            x + (((b * H + yy) * W + xx) * (long)C8 + c8) * 8);
+                        const uint32_t u[4] = {nv.x, nv.y, nv.z, nv.w};
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const float lo = bf16_bits_to_float(u[i] & 0xffffu);
+                            const float hi = bf16_bits_to_float(u[i] >> 16);
+                            if (lo > v[2 * i] || (before && lo == v[2 * i])) first[2 * i] = false;
+                            if (hi > v[2 * i + 1] || (before && hi == v[2 * i + 1]))
+                                first[2 * i + 1] = false;
                         }
                     }
                 }
-                if (first) g += bf16_bits_to_float(dy[((b * Ho + oy) * Wo + ox) * (long)C + c]);
+                const uint4 dv = *reinterpret_cast<const uint4*>(
+                    dy + (((b * Ho + oy) * Wo + ox) * (long)C8 + c8) * 8);
+                const uint32_t u[4] = {dv.x, dv.y, dv.z, dv.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (first[2 * i]) g[2 * i] += bf16_bits_to_float(u[i] & 0xffffu);
+                    if (first[2 * i + 1]) g[2 * i + 1] += bf16_bits_to_float(u[i] >> 16);
+                }
             }
         }
-        dx[e] = (uint16_t)float_to_bf16_bits(g);
+        uint4 o;
+        o.x = float_to_bf16_bits(g[0]) | (float_to_bf16_bits(g[1]) << 16);
+        o.y = float_to_bf16_bits(g[2]) | (float_to_bf16_bits(g[3]) << 16);
+        o.z = float_to_bf16_bits(g[4]) | (float_to_bf16_bits(g[5]) << 16);
+        o.w = float_to_bf16_bits(g[6]) | (float_to_bf16_bits(g[7]) << 16);
+        *reinterpret_cast<uint4*>(dx + e * 8) = o;
     }
 }
 
@@ -87,23 +117,37 @@ __global__ __launch_bounds__(256) void final_grad_prepare_kernel(const float* __
                                                                  int Kpad,
                                                                  uint16_t* __restrict__ out,
                                                                  float* __restrict__ dbias) {
+    // reads are coalesced along pixels (one plane per k); the [256 pixels][Kpad] tile is
+    // transposed through LDS so the bf16 rows leave as whole 16-byte chunks
+    extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ float red[32];
+    const int pitch = Kpad + 8;
+    uint16_t* tile = reinterpret_cast<uint16_t*>(smem);
     if (threadIdx.x < 32) red[threadIdx.x] = 0.0f;
     __syncthreads();
-    const long pix = (long)blockIdx.x * 256 + threadIdx.x;
+    const long pix0 = (long)blockIdx.x * 256;
+    const long pix = pix0 + threadIdx.x;
     const bool ok = pix < npix;
     const long b = ok ? pix / HW : 0;
     const int pl = ok ? (int)(pix - b * HW) : 0;
     for (int k = 0; k < Kpad; ++k) {
         float v = 0.0f;
         if (ok && k < K) v = g[(b * K + k) * HW + pl];
-        if (ok) out[pix * Kpad + k] = (uint16_t)float_to_bf16_bits(v);
+        tile[threadIdx.x * pitch + k] = (uint16_t)float_to_bf16_bits(v);
         if (k < K && dbias) {
             const float s = wave_sum(v);
             if ((threadIdx.x & 63) == 0) atomicAdd(&red[k], s);
         }
     }
     __syncthreads();
+    const int cpr = Kpad / 8;  // 16-byte chunks per pixel row
+    for (int ch = threadIdx.x; ch < 256 * cpr; ch += 256) {
+        const int row = ch / cpr;
+        const int cc = ch - row * cpr;
+        if (pix0 + row < npix)
+            *reinterpret_cast<uint4*>(out + (pix0 + row) * Kpad + cc * 8) =
+                *reinterpret_cast<const uint4*>(tile + row * pitch + cc * 8);
+    }
     if (dbias && threadIdx.x < K) atomicAdd(dbias + threadIdx.x, red[threadIdx.x]);
 }
 
@@ -360,9 +404,11 @@ extern "C" int32_t pe_transpose_weights_bf16(const void* in, int32_t A, int32_t 
 extern "C" int32_t pe_maxpool3x3s2_bwd_bf16(const void* x, const void* dy, int32_t B, int32_t H,
                                             int32_t W, int32_t C, void* dx, pe_stream_t stream) {
     PE_REQUIRE(x && dy && dx, PE_E_INVALID, "pe_maxpool3x3s2_bwd_bf16: NULL pointer");
-    PE_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && H % 2 == 0 && W % 2 == 0, PE_E_UNSUPPORTED,
-               "pe_maxpool3x3s2_bwd_bf16: need even H and W");
-    const long total = (long)B * H * W * C;
+    PE_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && H % 2 == 0 && W % 2 == 0 && C % 8 == 0,
+               PE_E_UNSUPPORTED, "pe_maxpool3x3s2_bwd_bf16: need even H, W and C %% 8 == 0");
+    PE_REQUIRE(aligned(x, 16) && aligned(dy, 16) && aligned(dx, 16), PE_E_INVALID,
+               "pe_maxpool3x3s2_bwd_bf16: tensors must be 16-byte aligned");
+    const long total = (long)B * H * W * (C / 8);
     long blocks = (total + 255) / 256;
     if (blocks > 256 * 32) blocks = 256 * 32;
     maxpool3x3s2_bwd_kernel<<<(unsigned)blocks, 256, 0, as_stream(stream)>>>(
@@ -375,10 +421,13 @@ extern "C" int32_t pe_final_grad_prepare_bf16(const float* g_nchw, int32_t B, in
                                               int32_t HW, int32_t Kpad, void* out_nhwc,
                                               float* dbias, pe_stream_t stream) {
     PE_REQUIRE(g_nchw && out_nhwc, PE_E_INVALID, "pe_final_grad_prepare_bf16: NULL pointer");
-    PE_REQUIRE(B > 0 && K > 0 && HW > 0 && K <= 32 && Kpad >= K, PE_E_UNSUPPORTED,
-               "pe_final_grad_prepare_bf16: need 0 < K <= 32 and Kpad >= K");
+    PE_REQUIRE(B > 0 && K > 0 && HW > 0 && K <= 32 && Kpad >= K && Kpad % 8 == 0 && Kpad <= 112,
+               PE_E_UNSUPPORTED,
+               "pe_final_grad_prepare_bf16: need 0 < K <= 32, Kpad >= K, Kpad %% 8 == 0, Kpad <= 112");
+    PE_REQUIRE(aligned(out_nhwc, 16), PE_E_INVALID, "pe_final_grad_prepare_bf16: output misaligned");
     const long npix = (long)B * HW;
-    final_grad_prepare_kernel<<<(unsigned)((npix + 255) / 256), 256, 0, as_stream(stream)>>>(
+    const size_t lds = (size_t)256 * (Kpad + 8) * sizeof(uint16_t);
+    final_grad_prepare_kernel<<<(unsigned)((npix + 255) / 256), 256, lds, as_stream(stream)>>>(
         g_nchw, npix, K, HW, Kpad, static_cast<uint16_t*>(out_nhwc), dbias);
     return check_launch("pe_final_grad_prepare_bf16");
 }

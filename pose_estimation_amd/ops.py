@@ -171,7 +171,7 @@ def mse_fwd_bwd(pred: torch.Tensor, target: Optional[torch.Tensor] = None,
             radius = int(round(3 * sigma))
     if mask is not None:
         if tuple(mask.shape) != (B, H, W):
-            raise ValueError("mask must be [B,H,W]")
+            raise ValueError(f"mask must be [B,H,W] = {(B, H, W)}, got {tuple(mask.shape)}")
         if mask.dtype == torch.bool:
             mask = mask.view(torch.uint8)
         if mask.dtype != torch.uint8:

@@ -1,0 +1,140 @@
+"""`Trainer`: the reference's entry object (`Trainer('config.yaml')`,
+`trainer.get_features_labels_data()`, test.ipynb:400-401) over the HIP training graph.
+
+The reference's Trainer built a tf.data pipeline and (presumably) an Estimator loop; neither
+survives in the snapshot.  This Trainer keeps the constructor and the `(features, labels)`
+batch shape (`features['images']`, `labels['heatmaps']` NHWC, `labels['masks']`), and adds the
+per-batch calls the hot path needs: `train_step`, `predict`, `decode`.
+"""
+from __future__ import annotations
+
+import os
+from typing import Dict, Iterator, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import ops, synthetic
+from .config import learning_rate_at, parse_config
+from .model import init_state
+from .training import TrainablePoseResNet
+
+
+class Trainer:
+    def __init__(self, config=None, device: Optional[str] = None):
+        cfg = parse_config(config)
+        self.data_cfg = cfg["data_config"]
+        self.train_cfg = cfg["train_config"]
+        self.model_cfg = cfg["model_config"]
+        if device is None:
+            device = f"cuda:{int(os.environ.get('LOCAL_RANK', '0'))}"
+        self.device = torch.device(device)
+        self.net: Optional[TrainablePoseResNet] = None
+        self.global_step = 0
+
+    # ------------------------------------------------------------------ model
+    def build_model(self, state: Optional[Dict[str, torch.Tensor]] = None, seed: int = 3):
+        m = self.model_cfg
+        if m.backbone != "resnet50":
+            raise NotImplementedError(f"backbone {m.backbone!r} is not built yet")
+        self.net = TrainablePoseResNet(self.device, num_joints=m.num_joints,
+                                       layers=tuple(m.layers), head_ch=m.head_channels,
+                                       bn_momentum=m.bn_momentum, sigma=m.sigma,
+                                       heatmap_stride=float(m.heatmap_stride))
+        self.net.load_state(state if state is not None else init_state(self.net.specs, seed))
+        import torch.distributed as dist
+
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            self.net.broadcast_parameters(0)
+            self.net.enable_data_parallel(int(m.bucket_mb) << 20)
+        return self.net
+
+    def _need_model(self) -> TrainablePoseResNet:
+        if self.net is None:
+            self.build_model()
+        return self.net
+
+    # ------------------------------------------------------------------ data (synthetic)
+    def get_features_labels_data(self, num_batches: Optional[int] = None
+                                 ) -> Iterator[Tuple[dict, dict]]:
+        """Yields (features, labels) in the reference's batch shape, labels rendered on the GPU
+        straight into the NHWC layout the reference's notebook reads (test.ipynb:919-931)."""
+        B = int(self.train_cfg.batch_size)
+        H, W = self.train_cfg.preprocess["image_resize"]
+        if H % 32 or W % 32:
+            raise ValueError(f"image_resize {H}x{W}: the network needs multiples of 32 "
+                             "(five stride-2 stages down, three up)")
+        K = int(self.model_cfg.num_joints)
+        s = int(self.model_cfg.heatmap_stride)
+        sigma = float(self.model_cfg.sigma)
+        i = 0
+        while num_batches is None or i < num_batches:
+            seed = int(self.data_cfg.seed) + 1000 * i
+            img = torch.from_numpy(synthetic.images_u8(B, H, W, seed + 1)).to(self.device)
+            joints = torch.from_numpy(synthetic.joints(B, K, H, W, seed + 2)).to(self.device)
+            mask = torch.from_numpy(synthetic.ignore_mask(B, H // s, W // s, seed + 4)).to(self.device)
+            hm, w = ops.render_targets(joints, H // s, W // s, float(s), sigma, layout="NHWC")
+            yield ({"images": img},
+                   {"heatmaps": hm, "masks": mask, "joints": joints, "weights": w})
+            i += 1
+
+    # ------------------------------------------------------------------ per-batch calls
+    def train_step(self, features, labels=None, mask=None):
+        """train_step(features_dict, labels_dict) or train_step(images_u8, joints[, mask]).
+        Returns the loss as a Python float is NOT done here (no sync): a [1] device tensor."""
+        net = self._need_model()
+        if isinstance(features, dict):
+            images, joints, mask = features["images"], labels["joints"], labels.get("masks")
+        else:
+            images, joints = features, labels
+        t = self.train_cfg
+        lr = learning_rate_at(t, self.global_step)
+        opt = t.optimizer
+        params = opt.get("params", {})
+        name = opt.get("name", "adam").lower()
+        if name == "adam":
+            loss, _ = net.train_step(images, joints, mask, lr=lr, optimizer="adam",
+                                     beta1=float(params.get("beta1", 0.9)),
+                                     beta2=float(params.get("beta2", 0.999)),
+                                     eps=float(params.get("epsilon", 1e-8)))
+        elif name in ("sgd", "momentum"):
+            loss, _ = net.train_step(images, joints, mask, lr=lr, optimizer="sgd",
+                                     momentum=float(params.get("momentum", 0.9)))
+        else:
+            raise ValueError(f"unknown optimizer {name!r}")
+        self.global_step += 1
+        return loss
+
+    def predict(self, images_u8: torch.Tensor) -> torch.Tensor:
+        """uint8 [B,H,W,3] -> float32 heat maps [B,K,H/4,W/4] (running BN statistics)."""
+        net = self._need_model()
+        net.fold_bn()
+        return net.predict(images_u8)
+
+    def decode(self, heatmaps: torch.Tensor, layout: str = "NCHW"):
+        """Heat maps -> (xy [B,K,2], conf [B,K], idx [B,K]) in heat-map cells."""
+        return ops.decode(heatmaps, layout=layout)
+
+    # ------------------------------------------------------------------ checkpoint
+    def save(self, path: str) -> None:
+        net = self._need_model()
+        torch.save({"master": net.master.cpu(), "opt_m": net.opt_m.cpu(), "opt_v": net.opt_v.cpu(),
+                    "bn_mean": {k: v.cpu() for k, v in net.bn_mean.items()},
+                    "bn_var": {k: v.cpu() for k, v in net.bn_var.items()},
+                    "step": net.step_count, "global_step": self.global_step}, path)
+
+    def load(self, path: str) -> None:
+        net = self._need_model()
+        ck = torch.load(path, weights_only=True)
+        net.master.copy_(ck["master"])
+        net.opt_m.copy_(ck["opt_m"])
+        net.opt_v.copy_(ck["opt_v"])
+        for k, v in ck["bn_mean"].items():
+            net.bn_mean[k].copy_(v)
+        for k, v in ck["bn_var"].items():
+            net.bn_var[k].copy_(v)
+        net.step_count = int(ck["step"])
+        self.global_step = int(ck["global_step"])
+        net.work.copy_(net.master)
+        net.refresh_transposes()
+        net.fold_bn()

@@ -1,0 +1,248 @@
+"""Training graph of the pose network on the HIP kernels: forward with batch statistics,
+fused target-render + masked-MSE loss, hand-written backward, bucketed data-parallel gradient
+exchange, fused Adam / SGD over the flat arenas.
+
+The reference's training loop (train.py / model/base_model.py, PoseEstimation.pyproj:30,34) is
+absent; its visible contract is `Trainer(config)`, Adam(0.9, 0.999, 1e-8), lr 1e-3 with
+exponential decay 0.95 / 10 000 steps (test.ipynb:400, 1001-1008) and Horovod-style data
+parallelism (test.ipynb:12): local batch statistics, summed gradients averaged over ranks.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+import torch
+
+from . import nn as pnn
+from . import ops
+from .model import BF16, BN_EPS, ConvSpec, PoseResNet
+from .parallel import GradBucketer
+
+FINAL_KPAD = 64  # the K-joint loss gradient is zero-padded to this many channels for the MFMA passes
+
+
+class TrainablePoseResNet(PoseResNet):
+    def __init__(self, device, num_joints: int = 17, layers=(3, 4, 6, 3), width: int = 64,
+                 head_ch: int = 256, bn_momentum: float = 0.1, sigma: float = 2.0,
+                 heatmap_stride: float = 4.0):
+        super().__init__(device, num_joints, layers, width, head_ch)
+        dev = self.device
+        self.bn_momentum = bn_momentum
+        self.sigma = sigma
+        self.radius = int(round(3 * sigma))
+        self.heatmap_stride = heatmap_stride
+        self.grads = torch.zeros(self.n_params, dtype=torch.float32, device=dev)
+        self.opt_m = torch.zeros(self.n_params, dtype=torch.float32, device=dev)
+        self.opt_v = torch.zeros(self.n_params, dtype=torch.float32, device=dev)
+        self.step_count = 0
+        # transposed weights for the backward-data passes
+        self.wt: Dict[str, torch.Tensor] = {}
+        for c in self.convs:
+            if c.kind == "conv":
+                self.wt[c.name] = torch.zeros(c.cin, c.k * c.k, c.cout, dtype=BF16, device=dev)
+            elif c.kind == "deconv":
+                self.wt[c.name] = torch.zeros(c.cin, 16, c.cout, dtype=BF16, device=dev)
+            elif c.kind == "final":
+                self.wt[c.name] = torch.zeros(c.cin, 1, FINAL_KPAD, dtype=BF16, device=dev)
+        self.bn_buf = {c.name: torch.empty(4, c.cout, dtype=torch.float32, device=dev)
+                       for c in self.convs if c.bn}
+        self._ws: Optional[torch.Tensor] = None
+        stem = self.specs[0]
+        self.stem_mask = pnn.pack_stem_weight(torch.ones(stem.cout, 3, 7, 7)).float().to(dev)
+        # layer start offsets in arena order (a layer = weight + its BN / bias vectors)
+        self.layer_starts: List[int] = [self.offsets[c.name + ".weight"][0] for c in self.convs]
+        self.bucketer: Optional[GradBucketer] = None
+        self.saved: dict = {}
+
+    # ------------------------------------------------------------------ set-up
+    def load_state(self, state) -> None:
+        super().load_state(state)
+        self.refresh_transposes()
+
+    def enable_data_parallel(self, bucket_bytes: int = 32 << 20, group=None) -> None:
+        """Call after torch.distributed is initialised; parameters must already be identical on
+        every rank (same seed / same loaded state, or broadcast_parameters())."""
+        self.bucketer = GradBucketer(self.grads, self.layer_starts, bucket_bytes, group)
+
+    def broadcast_parameters(self, src: int = 0) -> None:
+        import torch.distributed as dist
+
+        dist.broadcast(self.master, src)
+        for t in list(self.bn_mean.values()) + list(self.bn_var.values()):
+            dist.broadcast(t, src)
+        self.work.copy_(self.master)
+        self.refresh_transposes()
+
+    def refresh_transposes(self) -> None:
+        for c in self.convs:
+            w = self.w(c)
+            if c.kind == "conv":
+                pnn.transpose_weights(w.view(c.cout, c.k * c.k, c.cin), self.wt[c.name])
+            elif c.kind == "deconv":
+                for ph in range(4):
+                    pnn.transpose_weights(w[ph], self.wt[c.name], t0=4 * ph)
+            elif c.kind == "final":
+                pnn.transpose_weights(w.view(c.cout, 1, c.cin), self.wt[c.name])
+
+    def _workspace(self, z: torch.Tensor) -> torch.Tensor:
+        C = z.shape[3]
+        need = pnn.lib().pe_bn_workspace_bytes(z.numel() // C, C)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(max(need, 1 << 24), dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    def _gamma(self, c: ConvSpec):
+        return self.view(self.master, c.name + ".bn.gamma")
+
+    def _beta(self, c: ConvSpec):
+        return self.view(self.master, c.name + ".bn.beta")
+
+    def _g(self, name: str) -> torch.Tensor:
+        return self.view(self.grads, name)
+
+    # ------------------------------------------------------------------ forward (batch stats)
+    def _bn(self, c: ConvSpec, z: torch.Tensor, residual=None, relu=True) -> torch.Tensor:
+        _, _, scale, shift = pnn.bn_stats(z, self._gamma(c), self._beta(c), BN_EPS, self.bn_momentum,
+                                          self.bn_mean[c.name], self.bn_var[c.name],
+                                          self._workspace(z), out=self.bn_buf[c.name])
+        return pnn.bn_apply(z, scale, shift, residual, relu)
+
+    def block_forward(self, b, x: torch.Tensor) -> dict:
+        """One bottleneck block with batch statistics; returns everything backward needs."""
+        z1 = pnn.conv2d(x, self.w(b.c1))
+        a1 = self._bn(b.c1, z1)
+        z2 = pnn.conv2d(a1, self.w(b.c2), stride=b.c2.stride, pad=1)
+        a2 = self._bn(b.c2, z2)
+        z3 = pnn.conv2d(a2, self.w(b.c3))
+        zd = None
+        if b.down:
+            zd = pnn.conv2d(x, self.w(b.down), stride=b.down.stride)
+            idn = self._bn(b.down, zd, relu=False)
+        else:
+            idn = x
+        out = self._bn(b.c3, z3, residual=idn, relu=True)
+        return dict(x=x, z1=z1, a1=a1, z2=z2, a2=a2, z3=z3, zd=zd, out=out)
+
+    def block_backward(self, b, s: dict, dout: torch.Tensor) -> torch.Tensor:
+        """Backward of block_forward: accumulates the block's parameter gradients into the
+        gradient arena and returns the gradient with respect to the block input."""
+        x = s["x"]
+        hw_in = tuple(x.shape[1:3])
+        hw_mid = tuple(s["a1"].shape[1:3])
+        dz3, g3 = self._bn_bwd(b.c3, dout, s["out"], s["z3"], want_masked=True)
+        pnn.conv2d_bwd_weight(s["a2"], dz3, self._g(b.c3.name + ".weight"), 1, 1, 0)
+        da2 = pnn.conv2d_bwd_data(dz3, self.wt[b.c3.name], tuple(s["a2"].shape[1:3]), 1, 1, 0)
+        if b.down:
+            # the arena holds `down` after conv3, so it is finished before conv3 is marked
+            dzd, _ = self._bn_bwd(b.down, g3, None, s["zd"])
+            pnn.conv2d_bwd_weight(x, dzd, self._g(b.down.name + ".weight"), 1, b.down.stride, 0)
+            self._done(b.down)
+            res = pnn.conv2d_bwd_data(dzd, self.wt[b.down.name], hw_in, 1, b.down.stride, 0)
+        else:
+            res = g3
+        self._done(b.c3)
+        dz2, _ = self._bn_bwd(b.c2, da2, s["a2"], s["z2"])
+        pnn.conv2d_bwd_weight(s["a1"], dz2, self._g(b.c2.name + ".weight"), 3, b.c2.stride, 1)
+        self._done(b.c2)
+        da1 = pnn.conv2d_bwd_data(dz2, self.wt[b.c2.name], hw_mid, 3, b.c2.stride, 1)
+        dz1, _ = self._bn_bwd(b.c1, da1, s["a1"], s["z1"])
+        pnn.conv2d_bwd_weight(x, dz1, self._g(b.c1.name + ".weight"), 1, 1, 0)
+        self._done(b.c1)
+        return pnn.conv2d_bwd_data(dz1, self.wt[b.c1.name], hw_in, 1, 1, 0, residual=res)
+
+    def deconv_forward(self, d, x: torch.Tensor) -> dict:
+        z = pnn.deconv4x4s2(x, self.w(d))
+        return dict(x=x, z=z, a=self._bn(d, z))
+
+    def deconv_backward(self, d, s: dict, da: torch.Tensor) -> torch.Tensor:
+        dz, _ = self._bn_bwd(d, da, s["a"], s["z"])
+        pnn.deconv4x4s2_bwd_weight(s["x"], dz, self._g(d.name + ".weight"))
+        self._done(d)
+        return pnn.deconv4x4s2_bwd_data(dz, self.wt[d.name])
+
+    def forward_train(self, images_u8: torch.Tensor) -> torch.Tensor:
+        stem, blocks, deconvs, final = self.specs
+        sv: dict = {"blocks": [], "deconvs": []}
+        xs = pnn.preprocess_u8(images_u8)
+        z0 = pnn.stem7x7s2(xs, self.w(stem), None, None, relu=False)
+        a0 = self._bn(stem, z0)
+        x = pnn.maxpool3x3s2(a0)
+        sv.update(xs=xs, z0=z0, a0=a0)
+        for b in blocks:
+            s = self.block_forward(b, x)
+            sv["blocks"].append(s)
+            x = s["out"]
+        for d in deconvs:
+            s = self.deconv_forward(d, x)
+            sv["deconvs"].append(s)
+            x = s["a"]
+        sv["feat"] = x
+        hm = pnn.conv2d(x, self.w(final), None, self.view(self.master, final.name + ".bias"),
+                        out_f32_nchw=True)
+        self.saved = sv
+        return hm
+
+    # ------------------------------------------------------------------ backward
+    def _bn_bwd(self, c: ConvSpec, da, a, z, want_masked=False):
+        buf = self.bn_buf[c.name]
+        return pnn.bn_bwd(da, a, z, self._gamma(c), buf[0], buf[1], self._g(c.name + ".bn.gamma"),
+                          self._g(c.name + ".bn.beta"), self._workspace(z), want_masked)
+
+    def _done(self, c: ConvSpec) -> None:
+        if self.bucketer is not None:
+            self.bucketer.layer_done(self.offsets[c.name + ".weight"][0])
+
+    def backward(self, grad_hm: torch.Tensor) -> None:
+        """grad_hm: float32 [B,K,H,W] = dLoss/dHeatmaps.  Fills self.grads (pre-zeroed here)."""
+        stem, blocks, deconvs, final = self.specs
+        sv = self.saved
+        self.grads.zero_()
+        # final 1x1 conv + bias
+        dyp = pnn.final_grad_prepare(grad_hm, FINAL_KPAD, self._g(final.name + ".bias"))
+        pnn.conv2d_bwd_weight(sv["feat"], dyp, self._g(final.name + ".weight"), 1, 1, 0,
+                              cout=final.cout)
+        self._done(final)
+        H, W = sv["feat"].shape[1:3]
+        dx = pnn.conv2d_bwd_data(dyp, self.wt[final.name], (H, W), 1, 1, 0)
+        # deconv head
+        for d, s in zip(reversed(deconvs), reversed(sv["deconvs"])):
+            dx = self.deconv_backward(d, s, dx)
+        # bottleneck blocks
+        for b, s in zip(reversed(blocks), reversed(sv["blocks"])):
+            dx = self.block_backward(b, s, dx)
+        # stem
+        da0 = pnn.maxpool3x3s2_bwd(sv["a0"], dx)
+        dz0, _ = self._bn_bwd(stem, da0, sv["a0"], sv["z0"])
+        gw = self._g(stem.name + ".weight")
+        pnn.stem7x7s2_bwd_weight(sv["xs"], dz0, gw)
+        pnn.mul_(gw, self.stem_mask)
+        self._done(stem)
+
+    # ------------------------------------------------------------------ one optimisation step
+    def train_step(self, images_u8: torch.Tensor, joints: torch.Tensor,
+                   mask: Optional[torch.Tensor] = None, lr: float = 1e-3, optimizer: str = "adam",
+                   beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8,
+                   momentum: float = 0.9):
+        """images uint8 [B,H,W,3]; joints float32 [B,K,3] (x, y, v) in input pixels; mask
+        uint8 [B,H/4,W/4] or None.  Returns (loss [1] float32 device tensor, per_joint [K])."""
+        hm = self.forward_train(images_u8)
+        loss, per_joint, grad, _ = ops.mse_fwd_bwd(hm, joints=joints, mask=mask,
+                                                  stride=self.heatmap_stride, sigma=self.sigma,
+                                                  radius=self.radius)
+        self.backward(grad)
+        scale = 1.0
+        if self.bucketer is not None:
+            self.bucketer.finish()
+            scale = self.bucketer.grad_scale
+        self.step_count += 1
+        if optimizer == "adam":
+            ops.adam_step(self.master, self.opt_m, self.opt_v, self.grads, self.step_count, lr,
+                          beta1, beta2, eps, p_bf16=self.work, tf1=True, grad_scale=scale)
+        elif optimizer == "sgd":
+            ops.sgd_step(self.master, self.opt_m, self.grads, lr, momentum, p_bf16=self.work,
+                         grad_scale=scale)
+        else:
+            raise ValueError(f"unknown optimizer {optimizer!r}")
+        self.refresh_transposes()
+        self.saved = {}
+        return loss, per_joint

@@ -1,0 +1,88 @@
+"""Rehearsal of the data-parallel training path on ONE GPU: two ranks share cuda:0 and exchange
+gradients through gloo (RCCL refuses two ranks per device).  Not collected by pytest; run as
+    python tests/rehearse_dp.py
+It checks that after a step both ranks hold identical parameters and that the averaged gradient
+equals the mean of the two ranks' local gradients.
+"""
+import faulthandler
+import os
+import socket
+import sys
+import time
+from pathlib import Path
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+
+
+def log(rank, msg):
+    print(f"[rank {rank} {time.strftime('%H:%M:%S')}] {msg}", flush=True)
+
+
+def worker(rank, world, port):
+    faulthandler.dump_traceback_later(90, exit=True)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    log(rank, "process group up")
+    from pose_estimation_amd import model as pm
+    from pose_estimation_amd import synthetic
+    from pose_estimation_amd.training import TrainablePoseResNet
+
+    torch.cuda.set_device(0)
+    net = TrainablePoseResNet("cuda:0", layers=(1, 1, 1, 1))
+    net.load_state(pm.init_state(net.specs, seed=3))
+    net.enable_data_parallel(bucket_bytes=4 << 20)
+    log(rank, f"model built, {len(net.bucketer.buckets)} buckets")
+    B, H, W = 4, 64, 64
+    img = torch.from_numpy(synthetic.images_u8(B, H, W, seed=10 + rank)).cuda()
+    joints = torch.from_numpy(synthetic.joints(B, 17, H, W, seed=20 + rank)).cuda()
+
+    # local gradient without exchange, for the check
+    from pose_estimation_amd import ops
+
+    bucketer, net.bucketer = net.bucketer, None
+    hm = net.forward_train(img)
+    _, _, g, _ = ops.mse_fwd_bwd(hm, joints=joints, stride=4.0, sigma=2.0, radius=6)
+    net.backward(g)
+    local = net.grads.clone()
+    net.bucketer = bucketer
+    log(rank, "local gradient done")
+
+    hm = net.forward_train(img)
+    _, _, g, _ = ops.mse_fwd_bwd(hm, joints=joints, stride=4.0, sigma=2.0, radius=6)
+    net.backward(g)
+    log(rank, "backward with bucketed all-reduce issued")
+    net.bucketer.finish()
+    torch.cuda.synchronize()
+    log(rank, "all-reduce finished")
+    gathered = [torch.empty_like(local) for _ in range(world)]
+    dist.all_gather(gathered, local)
+    want = torch.stack(gathered).sum(0)
+    err = (net.grads - want).abs().max().item() / (want.abs().max().item() + 1e-30)
+    log(rank, f"summed gradient rel err {err:.2e}")
+    assert err < 1e-3, err   # float32 atomics reorder the two backward passes slightly
+
+    for i in range(3):
+        loss, _ = net.train_step(img, joints, lr=1e-3)
+        log(rank, f"step {i} loss {loss.item():.5f}")
+    masters = [torch.empty_like(net.master) for _ in range(world)]
+    dist.all_gather(masters, net.master)
+    assert torch.equal(masters[0], masters[1]), "ranks diverged"
+    log(rank, "parameters identical on both ranks")
+    dist.destroy_process_group()
+
+
+def main():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(worker, args=(2, port), nprocs=2, join=True)
+    print("rehearsal ok", flush=True)
+
+
+if __name__ == "__main__":
+    main()

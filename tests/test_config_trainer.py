@@ -1,0 +1,89 @@
+"""Host-side mirror of the reference interface: parse_config sections / keys and the Trainer
+surface (CPU part), then the Trainer end to end on the GPU."""
+import numpy as np
+import pytest
+import torch
+import yaml
+
+import pose_estimation_amd as pe
+from pose_estimation_amd.config import learning_rate_at, parse_config
+
+
+def test_parse_config_defaults_match_the_reference_notebook(golden_dir):
+    import json
+
+    fix = json.loads((golden_dir / "reference_notebook_fixture.json").read_text())
+    cfg = parse_config()
+    assert set(cfg) == {"data_config", "train_config", "model_config"}   # test.ipynb:384-386
+    t = cfg["train_config"]
+    assert t.learning_rate == fix["adam"]["learning_rate"]
+    assert t.optimizer["name"] == "adam"
+    assert t.optimizer["params"]["beta1"] == fix["adam"]["beta1"]
+    assert t.optimizer["params"]["beta2"] == fix["adam"]["beta2"]
+    assert t.optimizer["params"]["epsilon"] == fix["adam"]["epsilon"]     # a string, as printed
+    assert float(t.optimizer["params"]["epsilon"]) == 1e-8
+    assert t.learning_rate_decay == {"decay_rate": fix["adam"]["decay_rate"],
+                                     "decay_steps": fix["adam"]["decay_steps"]}
+    assert "batch_size" in t.__dict__ and t.batch_size == 2               # test.ipynb:962
+
+
+def test_parse_config_yaml_overrides(tmp_path):
+    p = tmp_path / "config.yaml"
+    p.write_text(yaml.safe_dump({
+        "train_config": {"batch_size": 64, "optimizer": {"name": "sgd", "params": {"momentum": 0.8}},
+                         "preprocess": {"image_resize": [384, 288]}},
+        "model_config": {"num_joints": 3, "sigma": 3.0},
+    }))
+    cfg = parse_config(str(p))
+    assert cfg["train_config"].batch_size == 64
+    assert cfg["train_config"].optimizer["name"] == "sgd"
+    assert cfg["train_config"].optimizer["params"]["momentum"] == 0.8
+    assert cfg["train_config"].learning_rate == 0.001                      # default kept
+    assert cfg["model_config"].num_joints == 3 and cfg["model_config"].sigma == 3.0
+    assert cfg["model_config"].layers == [3, 4, 6, 3]
+    with pytest.raises(KeyError):
+        parse_config({"trian_config": {}})
+
+
+def test_learning_rate_schedule():
+    t = parse_config()["train_config"]
+    assert learning_rate_at(t, 0) == pytest.approx(1e-3)
+    assert learning_rate_at(t, 10000) == pytest.approx(0.95e-3)
+    assert learning_rate_at(t, 5000) == pytest.approx(1e-3 * 0.95 ** 0.5)
+
+
+def test_trainer_constructs_without_a_gpu():
+    tr = pe.Trainer({"train_config": {"batch_size": 4}}, device="cpu")
+    assert tr.train_cfg.batch_size == 4 and tr.net is None
+
+
+@pytest.mark.gpu
+def test_trainer_end_to_end(tmp_path):
+    cfg = {"train_config": {"batch_size": 4, "preprocess": {"image_resize": [64, 96]}},
+           "model_config": {"layers": [1, 1, 1, 1]}}
+    tr = pe.Trainer(cfg)
+    tr.build_model(seed=5)
+    batches = list(tr.get_features_labels_data(num_batches=2))
+    features, labels = batches[0]
+    assert features["images"].shape == (4, 64, 96, 3) and features["images"].dtype == torch.uint8
+    assert labels["heatmaps"].shape == (4, 16, 24, 17)                    # NHWC, as the reference
+    assert labels["masks"].shape == (4, 16, 24)
+    # labels decode back to the joints they were rendered from
+    xy, conf, idx = tr.decode(labels["heatmaps"], layout="NHWC")
+    on = labels["weights"] > 0
+    centre = torch.floor(labels["joints"][..., :2] / 4.0 + 0.5)
+    inside = on & (centre[..., 0] >= 0) & (centre[..., 0] < 24) & (centre[..., 1] >= 0) & (centre[..., 1] < 16)
+    assert torch.equal(xy[inside].round(), centre[inside])
+    losses = [tr.train_step(features, labels).item() for _ in range(6)]
+    assert losses[-1] < losses[0]
+    hm = tr.predict(features["images"])
+    assert hm.shape == (4, 17, 16, 24) and torch.isfinite(hm).all()
+    # checkpoint round trip
+    path = str(tmp_path / "ck.pt")
+    tr.save(path)
+    tr2 = pe.Trainer(cfg)
+    tr2.build_model(seed=99)
+    tr2.load(path)
+    assert torch.equal(tr2.net.master, tr.net.master)
+    assert torch.equal(tr2.predict(features["images"]), hm)
+    assert tr2.global_step == 6
