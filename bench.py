@@ -356,7 +356,8 @@ def main() -> None:
     dev_ms = ev0.elapsed_time(ev1)  # same stream as the launches (torch's current stream)
 
     if dist is not None:
-        t = torch.tensor([elapsed, dev_ms], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed, dev_ms], dtype=torch.float64,
+                         device="cpu" if rehearse else device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed, dev_ms = float(t[0]), float(t[1])
 

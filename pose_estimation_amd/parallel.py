@@ -51,6 +51,12 @@ class GradBucketer:
         self.group = group
         self.arena = arena
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        # RCCL (and gloo on CPU tensors) overlap with backward through async ops.  gloo on GPU
+        # tensors exists only to rehearse the N > 1 path on a one-GPU box; its device-tensor
+        # collectives stall from the second round on (observed on ROCm), so that combination
+        # stages each bucket through host memory and reduces it synchronously.
+        backend = dist.get_backend(group) if dist.is_initialized() else "none"
+        self._staged = backend == "gloo" and arena.is_cuda
         elems = max(1, bucket_bytes // arena.element_size())
         self.buckets = make_buckets(boundaries, arena.numel(), elems)
         self._ready_at = {start: (start, end) for (start, end) in self.buckets}
@@ -69,7 +75,13 @@ class GradBucketer:
         if b is None:
             return
         start, end = b
-        self._pending.append(self.dist.all_reduce(self.arena[start:end], op=self.dist.ReduceOp.SUM,
+        view = self.arena[start:end]
+        if self._staged:
+            host = view.cpu()
+            self.dist.all_reduce(host, op=self.dist.ReduceOp.SUM, group=self.group)
+            view.copy_(host)
+            return
+        self._pending.append(self.dist.all_reduce(view, op=self.dist.ReduceOp.SUM,
                                                   group=self.group, async_op=True))
 
     def finish(self) -> None:

@@ -41,9 +41,16 @@ def worker(rank, world, port):
     img = torch.from_numpy(synthetic.images_u8(B, H, W, seed=10 + rank)).cuda()
     joints = torch.from_numpy(synthetic.joints(B, 17, H, W, seed=20 + rank)).cuda()
 
-    # local gradient without exchange, for the check
     from pose_estimation_amd import ops
 
+    if os.environ.get("REH_STEPS_ONLY") == "1":
+        for i in range(3):
+            loss, _ = net.train_step(img, joints, lr=1e-3)
+            log(rank, f"step {i} loss {loss.item():.5f}")
+        dist.destroy_process_group()
+        return
+
+    # local gradient without exchange, for the check
     bucketer, net.bucketer = net.bucketer, None
     hm = net.forward_train(img)
     _, _, g, _ = ops.mse_fwd_bwd(hm, joints=joints, stride=4.0, sigma=2.0, radius=6)
@@ -59,18 +66,20 @@ def worker(rank, world, port):
     net.bucketer.finish()
     torch.cuda.synchronize()
     log(rank, "all-reduce finished")
+    local = local.cpu()   # gloo collectives on host tensors only (see parallel.py)
     gathered = [torch.empty_like(local) for _ in range(world)]
     dist.all_gather(gathered, local)
     want = torch.stack(gathered).sum(0)
-    err = (net.grads - want).abs().max().item() / (want.abs().max().item() + 1e-30)
+    err = (net.grads.cpu() - want).abs().max().item() / (want.abs().max().item() + 1e-30)
     log(rank, f"summed gradient rel err {err:.2e}")
     assert err < 1e-3, err   # float32 atomics reorder the two backward passes slightly
 
     for i in range(3):
         loss, _ = net.train_step(img, joints, lr=1e-3)
         log(rank, f"step {i} loss {loss.item():.5f}")
-    masters = [torch.empty_like(net.master) for _ in range(world)]
-    dist.all_gather(masters, net.master)
+    mine = net.master.cpu()
+    masters = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(masters, mine)
     assert torch.equal(masters[0], masters[1]), "ranks diverged"
     log(rank, "parameters identical on both ranks")
     dist.destroy_process_group()
