@@ -301,6 +301,260 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Direct-to-LDS variant (the default).  Tiles go global -> LDS with global_load_lds_dwordx4
+// (16 B per lane, no VGPR staging, no ds_write pass); one LDS buffer of 128-byte rows, two
+// barriers per K step, and 3-4 workgroups per CU so that other workgroups' MFMAs cover a
+// workgroup's load latency.  A wave instruction writes 1 KiB = 8 consecutive rows, lane l to
+// (row l>>3, 16-byte slot l&7); LDS rows are unpadded, so bank conflicts are avoided by an XOR
+// swizzle: slot s of row r holds K-chunk s ^ (r & 7).  The swizzle is applied to the per-lane
+// SOURCE address (the LDS destination of a global_load_lds is not a per-lane choice) and again
+// when fragments are read.  Out-of-range rows / taps read a 16-byte block of zeros instead.
+// The epilogue stages the fp32 tile through LDS in two column halves (<= 35 KB) so stores and
+// residual loads are whole lines.
+// ---------------------------------------------------------------------------------------------
+__device__ __attribute__((aligned(16))) uint32_t g_zero16[4] = {0u, 0u, 0u, 0u};
+
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+template <int BN>
+__global__ __launch_bounds__(256, 3) void igemm_glds_kernel(const IgemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int TM = 4;
+    constexpr int TN = BN / 32;
+    constexpr int WROWS = BN / 32;
+    constexpr int ROWB = 128;                 // bytes per LDS row (64 bf16, unpadded)
+    constexpr int XBYTES = BM * ROWB;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wid = tid >> 6;
+    const int wave_m = wid >> 1;
+    const int wave_n = wid & 1;
+
+    const long M = (long)p.B * p.Ho * p.Wo;
+    const int ntn = (p.N + BN - 1) / BN;
+    int bid = blockIdx.x;
+    {
+        const int nwg = gridDim.x;
+        const int q = nwg >> 3, r = nwg & 7;
+        const int xcd = bid & 7, loc = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    }
+    const int tile_m = bid / ntn;
+    const int tile_n = bid - tile_m * ntn;
+    const long m0 = (long)tile_m * BM;
+    const int n0 = tile_n * BN;
+
+    // staging: wave w, instruction i covers rows 32*i + 8*w .. +7; lane l -> row +(l>>3), slot l&7,
+    // which must receive K-chunk (l&7) ^ (row&7) = (l&7) ^ ((l>>3)&7)
+    const int r0 = tid >> 3;                              // = 8*w + (l>>3)
+    const int cc = (lane & 7) ^ ((lane >> 3) & 7);        // logical K-chunk this lane fetches
+    const int HoWo = p.Ho * p.Wo;
+    int iy0[4], ix0[4], pixbase[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const long m = m0 + r0 + 32 * i;
+        if (m < M) {
+            const int b = (int)(m / HoWo);
+            const int rem = (int)(m - (long)b * HoWo);
+            const int oy = rem / p.Wo;
+            const int ox = rem - oy * p.Wo;
+            iy0[i] = oy * p.sy;
+            ix0[i] = ox * p.sx;
+            pixbase[i] = b * p.Hi * p.Wi;
+        } else {
+            iy0[i] = -(1 << 20);
+            ix0[i] = 0;
+            pixbase[i] = 0;
+        }
+    }
+    const int kc = p.Cin / BK;
+    const int KT = p.T * kc;
+    const long ktot = p.wk_row;
+    const uint16_t* zero = reinterpret_cast<const uint16_t*>(g_zero16);
+
+    f32x4 acc[TN][TM];
+#pragma unroll
+    for (int a = 0; a < TN; ++a)
+#pragma unroll
+        for (int b = 0; b < TM; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int lr = lane & 15;
+    const int sw = lane & 7;   // (row & 7) of every fragment row this lane reads
+    const char* xs = smem + (wave_m * 64 + lr) * ROWB;
+    const char* ws = smem + XBYTES + (wave_n * (BN / 2) + lr) * ROWB;
+
+    int tap = 0, cstep = 0;
+    for (int kt = 0; kt < KT; ++kt) {
+        // ---- issue this K step's loads straight into LDS
+        {
+            const int dy = p.tap_dy[tap];
+            const int dx = p.tap_dx[tap];
+            const int coff = cstep * BK + cc * 8;
+            const long wk = (long)p.tap_slot[tap] * p.Cin + coff;
+            const int xextra = coff >> p.cshift;
+            const int ch = coff & p.cmask;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int iy = iy0[i] + dy;
+                const int ix = ix0[i] + dx + xextra;
+                const bool ok = (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+                const long off = (long)(pixbase[i] + iy * p.Wi + ix) * p.Cx + ch;
+                const uint16_t* src = ok ? p.x + off : zero;
+                __builtin_amdgcn_global_load_lds((gptr_t)src,
+                                                 (lptr_t)(smem + (32 * i + 8 * wid) * ROWB), 16, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < WROWS; ++i) {
+                const int n = n0 + r0 + 32 * i;
+                const uint16_t* src = (n < p.N) ? p.w + ((long)n * ktot + wk) : zero;
+                __builtin_amdgcn_global_load_lds(
+                    (gptr_t)src, (lptr_t)(smem + XBYTES + (32 * i + 8 * wid) * ROWB), 16, 0, 0);
+            }
+            if (++cstep == kc) {
+                cstep = 0;
+                ++tap;
+            }
+        }
+        __syncthreads();   // the compiler drains vmcnt before this barrier: tile is in LDS
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 af[TN], bfr[TM];
+            const int slot0 = ((kk * 4 + (lane >> 4)) ^ sw) * 16;
+#pragma unroll
+            for (int a = 0; a < TN; ++a)
+                af[a] = *reinterpret_cast<const bf16x8*>(ws + a * 16 * ROWB + slot0);
+#pragma unroll
+            for (int b = 0; b < TM; ++b)
+                bfr[b] = *reinterpret_cast<const bf16x8*>(xs + b * 16 * ROWB + slot0);
+#pragma unroll
+            for (int a = 0; a < TN; ++a)
+#pragma unroll
+                for (int b = 0; b < TM; ++b)
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bfr[b], acc[a][b], 0, 0, 0);
+        }
+        __syncthreads();   // everyone is done reading before the next K step overwrites the tile
+    }
+
+    // ---- epilogue
+    const bool identity = (p.osy == 1 && p.osx == 1 && p.ooy == 0 && p.oox == 0 &&
+                           p.OH == p.Ho && p.OW == p.Wo);
+    const int OHW = p.OH * p.OW;
+    const int nq = (lane >> 4) * 4;
+
+    if (p.out_mode == 0 && (p.N & 7) == 0 && (p.ldc & 7) == 0) {
+        constexpr int HALF = BN / 2;       // columns staged per pass (one wave_n half)
+        constexpr int CP = HALF + 4;       // float pitch: 8-lane ds_write_b128 groups hit distinct banks
+        constexpr int CPR = HALF / 8;      // 16-byte output chunks per pixel row
+        constexpr int RPP = 256 / CPR;     // pixel rows per pass of the store loop
+        float* cs = reinterpret_cast<float*>(smem);
+        const int chunk = tid % CPR;
+        const int prow = tid / CPR;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            if (wave_n == half) {
+#pragma unroll
+                for (int a = 0; a < TN; ++a) {
+                    const int col = a * 16 + nq;
+                    const int n = n0 + half * HALF + col;
+                    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+                    if (n < p.N) {
+                        if (p.scale) sc = *reinterpret_cast<const f32x4*>(p.scale + n);
+                        if (p.shift) sh = *reinterpret_cast<const f32x4*>(p.shift + n);
+                    }
+#pragma unroll
+                    for (int b = 0; b < TM; ++b) {
+                        const int pr = wave_m * 64 + b * 16 + lr;
+                        *reinterpret_cast<f32x4*>(cs + pr * CP + col) = acc[a][b] * sc + sh;
+                    }
+                }
+            }
+            __syncthreads();
+            const int n = n0 + half * HALF + chunk * 8;
+            if (n < p.N) {
+#pragma unroll
+                for (int pass = 0; pass < BM / RPP; ++pass) {
+                    const int pr = prow + pass * RPP;
+                    const long m = m0 + pr;
+                    if (m >= M) break;
+                    long opix = m;
+                    if (!identity) {
+                        const int bb = (int)(m / HoWo);
+                        const int rem = (int)(m - (long)bb * HoWo);
+                        const int oy = rem / p.Wo;
+                        const int ox = rem - oy * p.Wo;
+                        opix = (long)bb * OHW + (oy * p.osy + p.ooy) * p.OW + ox * p.osx + p.oox;
+                    }
+                    const f32x4 v0 = *reinterpret_cast<const f32x4*>(cs + pr * CP + chunk * 8);
+                    const f32x4 v1 = *reinterpret_cast<const f32x4*>(cs + pr * CP + chunk * 8 + 4);
+                    float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+                    if (p.res) {
+                        const uint4 rv = *reinterpret_cast<const uint4*>(p.res + opix * p.ldc + n);
+                        const uint32_t u[4] = {rv.x, rv.y, rv.z, rv.w};
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            v[2 * i] += bf16_bits_to_float(u[i] & 0xffffu);
+                            v[2 * i + 1] += bf16_bits_to_float(u[i] >> 16);
+                        }
+                    }
+                    if (p.relu) {
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) v[i] = fmaxf(v[i], 0.0f);
+                    }
+                    uint4 o;
+                    o.x = pack_bf16x2(v[0], v[1]);
+                    o.y = pack_bf16x2(v[2], v[3]);
+                    o.z = pack_bf16x2(v[4], v[5]);
+                    o.w = pack_bf16x2(v[6], v[7]);
+                    *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(p.y) + opix * p.ldc + n) = o;
+                }
+            }
+            __syncthreads();
+        }
+        return;
+    }
+
+    // general path: channel counts that are not multiples of 8, float32 NCHW output
+#pragma unroll
+    for (int b = 0; b < TM; ++b) {
+        const long m = m0 + wave_m * 64 + b * 16 + lr;
+        if (m >= M) continue;
+        const int bb = (int)(m / HoWo);
+        const int rem = (int)(m - (long)bb * HoWo);
+        const int oy = rem / p.Wo;
+        const int ox = rem - oy * p.Wo;
+        const int opl = (oy * p.osy + p.ooy) * p.OW + ox * p.osx + p.oox;
+        const long opix = (long)bb * OHW + opl;
+#pragma unroll
+        for (int a = 0; a < TN; ++a) {
+            const int n = n0 + wave_n * (BN / 2) + a * 16 + nq;
+            const float v[4] = {acc[a][b].x, acc[a][b].y, acc[a][b].z, acc[a][b].w};
+            for (int j = 0; j < 4 && n + j < p.N; ++j) {
+                float t = v[j] * (p.scale ? p.scale[n + j] : 1.0f) + (p.shift ? p.shift[n + j] : 0.0f);
+                if (p.out_mode == 0) {
+                    if (p.res) t += bf16_bits_to_float(p.res[opix * p.ldc + n + j]);
+                    if (p.relu) t = fmaxf(t, 0.0f);
+                    reinterpret_cast<uint16_t*>(p.y)[opix * p.ldc + n + j] = (uint16_t)float_to_bf16_bits(t);
+                } else {
+                    if (p.relu) t = fmaxf(t, 0.0f);
+                    reinterpret_cast<float*>(p.y)[((long)bb * p.N + n + j) * OHW + opl] = t;
+                }
+            }
+        }
+    }
+}
+
+static bool use_regstage() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("PE_IGEMM_REGSTAGE");
+        v = (e && e[0] == '1') ? 1 : 0;
+    }
+    return v == 1;
+}
+
 int32_t igemm_launch(const IgemmParams& pin, hipStream_t st, const char* what) {
     IgemmParams p = pin;
     if (p.wk_row == 0) p.wk_row = p.T * p.Cin;
@@ -333,13 +587,24 @@ int32_t igemm_launch(const IgemmParams& pin, hipStream_t st, const char* what) {
                                   2 * (BM + 64) * LDS_ROW * 2);
         attr_set = true;
     }
+    if (use_regstage()) {  // register-staged variant, kept for A/B timing in one binary
+        if (p.N > 64) {
+            const long ntn = (p.N + 127) / 128;
+            const size_t lds = 2 * (BM + 128) * LDS_ROW * sizeof(uint16_t);
+            igemm_kernel<128><<<(unsigned)(ntm * ntn), 256, lds, st>>>(p);
+        } else {
+            const size_t lds = 2 * (BM + 64) * LDS_ROW * sizeof(uint16_t);
+            igemm_kernel<64><<<(unsigned)ntm, 256, lds, st>>>(p);
+        }
+        return check_launch(what);
+    }
     if (p.N > 64) {
         const long ntn = (p.N + 127) / 128;
-        const size_t lds = 2 * (BM + 128) * LDS_ROW * sizeof(uint16_t);
-        igemm_kernel<128><<<(unsigned)(ntm * ntn), 256, lds, st>>>(p);
+        const size_t lds = BM * (64 + 4) * sizeof(float);          // epilogue half tile > K tile
+        igemm_glds_kernel<128><<<(unsigned)(ntm * ntn), 256, lds, st>>>(p);
     } else {
-        const size_t lds = 2 * (BM + 64) * LDS_ROW * sizeof(uint16_t);
-        igemm_kernel<64><<<(unsigned)ntm, 256, lds, st>>>(p);
+        const size_t lds = (BM + 64) * 128;                         // K tile > epilogue half tile
+        igemm_glds_kernel<64><<<(unsigned)ntm, 256, lds, st>>>(p);
     }
     return check_launch(what);
 }
