@@ -144,40 +144,46 @@ extern "C" int32_t pe_deconv4x4s2_fwd_bf16(int32_t B, int32_t H, int32_t W, int3
                                            const float* shift, void* y, pe_stream_t stream) {
     PE_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, PE_E_INVALID,
                "pe_deconv4x4s2_fwd_bf16: sizes must be positive");
+    // the four output-parity phases run in one launch (gridDim.y = 4)
+    IgemmParams p;
+    base_params(p);
+    p.x = static_cast<const uint16_t*>(x);
+    p.w = static_cast<const uint16_t*>(w_phases);
+    p.y = y;
+    p.scale = scale;
+    p.shift = shift;
+    p.B = B;
+    p.Hi = H;
+    p.Wi = W;
+    p.Cx = Cin;
+    p.Cin = Cin;
+    p.N = Cout;
+    p.wk_row = 4 * Cin;
+    p.nphase = 4;
     for (int py = 0; py < 2; ++py)
         for (int px = 0; px < 2; ++px) {
-            IgemmParams p;
-            base_params(p);
-            p.x = static_cast<const uint16_t*>(x);
-            p.w = static_cast<const uint16_t*>(w_phases) + (size_t)(2 * py + px) * Cout * 4 * Cin;
-            p.y = y;
-            p.scale = scale;
-            p.shift = shift;
-            p.B = B;
-            p.Hi = H;
-            p.Wi = W;
-            p.Cx = Cin;
-            p.Cin = Cin;
-            p.Ho = H;
-            p.Wo = W;
-            p.N = Cout;
-            p.T = 4;
+            const int ph = 2 * py + px;
+            p.ph_t0[ph] = (int16_t)(4 * ph);
+            p.ph_T[ph] = 4;
+            p.ph_ooy[ph] = (int16_t)py;
+            p.ph_oox[ph] = (int16_t)px;
+            p.ph_Ho[ph] = H;
+            p.ph_Wo[ph] = W;
+            p.ph_woff[ph] = (long)ph * Cout * 4 * Cin;
             for (int a = 0; a < 2; ++a)
                 for (int b = 0; b < 2; ++b) {
-                    p.tap_dy[2 * a + b] = (int16_t)(a == 0 ? 0 : (py == 0 ? -1 : 1));
-                    p.tap_dx[2 * a + b] = (int16_t)(b == 0 ? 0 : (px == 0 ? -1 : 1));
+                    const int t = 4 * ph + 2 * a + b;
+                    p.tap_dy[t] = (int16_t)(a == 0 ? 0 : (py == 0 ? -1 : 1));
+                    p.tap_dx[t] = (int16_t)(b == 0 ? 0 : (px == 0 ? -1 : 1));
+                    p.tap_slot[t] = (uint8_t)(2 * a + b);
                 }
-            p.OH = 2 * H;
-            p.OW = 2 * W;
-            p.osy = p.osx = 2;
-            p.ooy = py;
-            p.oox = px;
-            p.ldc = Cout;
-            p.relu = relu;
-            const int32_t rc = igemm_launch(p, as_stream(stream), "pe_deconv4x4s2_fwd_bf16");
-            if (rc != PE_OK) return rc;
         }
-    return PE_OK;
+    p.OH = 2 * H;
+    p.OW = 2 * W;
+    p.osy = p.osx = 2;
+    p.ldc = Cout;
+    p.relu = relu;
+    return igemm_launch(p, as_stream(stream), "pe_deconv4x4s2_fwd_bf16");
 }
 
 extern "C" int32_t pe_stem7x7s2_fwd_bf16(int32_t B, int32_t H2, int32_t W2, int32_t Cout,

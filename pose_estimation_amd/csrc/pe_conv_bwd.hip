@@ -195,11 +195,15 @@ extern "C" int32_t pe_conv2d_bwd_data_bf16(const pe_conv_desc* d, const void* dy
         PE_REQUIRE(e == hipSuccess, PE_E_HIP, "pe_conv2d_bwd_data_bf16: memset: %s",
                    hipGetErrorString(e));
     }
+    // every input-parity class that has taps becomes one phase of a single launch
+    IgemmParams p;
+    igemm_defaults(p);
+    int t = 0, nph = 0;
     for (int py = 0; py < s; ++py)
         for (int px = 0; px < s; ++px) {
-            IgemmParams p;
-            igemm_defaults(p);
-            int t = 0;
+            const int Hp = (d->H - py + s - 1) / s, Wp = (d->W - px + s - 1) / s;
+            if (Hp <= 0 || Wp <= 0) continue;
+            const int tstart = t;
             for (int kh = 0; kh < d->KH; ++kh)
                 for (int kw = 0; kw < d->KW; ++kw) {
                     const int ny = py + d->pad - kh, nx = px + d->pad - kw;
@@ -209,33 +213,34 @@ extern "C" int32_t pe_conv2d_bwd_data_bf16(const pe_conv_desc* d, const void* dy
                     p.tap_slot[t] = (uint8_t)(kh * d->KW + kw);
                     ++t;
                 }
-            if (t == 0) continue;
-            const int Hp = (d->H - py + s - 1) / s, Wp = (d->W - px + s - 1) / s;
-            if (Hp <= 0 || Wp <= 0) continue;
-            p.x = static_cast<const uint16_t*>(dy);
-            p.w = static_cast<const uint16_t*>(w_t);
-            p.y = dx;
-            p.res = static_cast<const uint16_t*>(residual);
-            p.B = d->B;
-            p.Hi = Ho;
-            p.Wi = Wo;
-            p.Cx = d->Cout;
-            p.Cin = d->Cout;
-            p.Ho = Hp;
-            p.Wo = Wp;
-            p.N = d->Cin;
-            p.T = t;
-            p.wk_row = T * d->Cout;
-            p.OH = d->H;
-            p.OW = d->W;
-            p.osy = p.osx = s;
-            p.ooy = py;
-            p.oox = px;
-            p.ldc = d->Cin;
-            const int32_t rc = igemm_launch(p, st, "pe_conv2d_bwd_data_bf16");
-            if (rc != PE_OK) return rc;
+            if (t == tstart) continue;
+            p.ph_t0[nph] = (int16_t)tstart;
+            p.ph_T[nph] = (int16_t)(t - tstart);
+            p.ph_ooy[nph] = (int16_t)py;
+            p.ph_oox[nph] = (int16_t)px;
+            p.ph_Ho[nph] = Hp;
+            p.ph_Wo[nph] = Wp;
+            p.ph_woff[nph] = 0;
+            ++nph;
         }
-    return PE_OK;
+    PE_REQUIRE(nph > 0, PE_E_INVALID, "pe_conv2d_bwd_data_bf16: no taps reach the input");
+    p.nphase = nph;
+    p.x = static_cast<const uint16_t*>(dy);
+    p.w = static_cast<const uint16_t*>(w_t);
+    p.y = dx;
+    p.res = static_cast<const uint16_t*>(residual);
+    p.B = d->B;
+    p.Hi = Ho;
+    p.Wi = Wo;
+    p.Cx = d->Cout;
+    p.Cin = d->Cout;
+    p.N = d->Cin;
+    p.wk_row = T * d->Cout;
+    p.OH = d->H;
+    p.OW = d->W;
+    p.osy = p.osx = s;
+    p.ldc = d->Cin;
+    return igemm_launch(p, st, "pe_conv2d_bwd_data_bf16");
 }
 
 extern "C" int32_t pe_deconv4x4s2_bwd_data_bf16(int32_t B, int32_t H, int32_t W, int32_t Cin,

@@ -16,6 +16,7 @@
 namespace pe {
 
 constexpr int kMaxTaps = 64;
+constexpr int kMaxPhases = 4;
 
 struct IgemmParams {
     const uint16_t* x;      // activations, NHWC bf16, Cx channels per pixel
@@ -40,6 +41,13 @@ struct IgemmParams {
     int16_t tap_dy[kMaxTaps];
     int16_t tap_dx[kMaxTaps];
     uint8_t tap_slot[kMaxTaps];  // position of each tap's Cin-block inside a weight row
+    // Optional phases (gridDim.y): phase i uses taps [ph_t0[i], ph_t0[i] + ph_T[i]), the row grid
+    // ph_Ho[i] x ph_Wo[i], output offset (ph_ooy[i], ph_oox[i]) and weights w + ph_woff[i].
+    // nphase == 0: one phase taken from T, Ho, Wo, ooy, oox.
+    int nphase;
+    int16_t ph_t0[kMaxPhases], ph_T[kMaxPhases], ph_ooy[kMaxPhases], ph_oox[kMaxPhases];
+    int ph_Ho[kMaxPhases], ph_Wo[kMaxPhases];
+    long ph_woff[kMaxPhases];
 };
 
 // Neutral defaults: unit strides, identity scatter, densely packed taps, single-pixel K runs.

@@ -1,36 +1,55 @@
-// Implicit-GEMM convolution kernel: bf16 MFMA 16x16x32, fp32 accumulate, LDS-staged tiles.
+// Implicit-GEMM convolution kernel: bf16 MFMA 16x16x32, fp32 accumulate, direct-to-LDS tiles.
 //
-// Workgroup = 256 threads = 4 waves (2 along m x 2 along n), output tile 128 (pixels) x BN
-// (channels), K step 64.  Activations and weights are staged global -> registers -> LDS with the
-// next K step's global loads in flight while the current one is multiplied (two LDS buffers,
-// one barrier per K step).  LDS rows are 64 + 16 bf16 (160 B): with that pitch the 16-lane groups
-// of ds_read_b128 touch 16 distinct 16-byte bank slots, so fragment reads are conflict-free.
+// Workgroup = 256 threads = 4 waves (2 along m x 2 along n), output tile BM (pixels: 128 or 64)
+// x BN (channels: 128 or 64), K step 64.  Tiles go global -> LDS with global_load_lds_dwordx4
+// (16 B per lane, no VGPR staging, no ds_write pass) into ONE buffer of 128-byte rows; two
+// barriers per K step; 128 VGPRs and <= 35 KB of LDS so four workgroups share a CU and their
+// MFMAs cover each other's load latency.  (A register-staged, double-buffered variant of this
+// kernel ran 25 % slower end to end in the same binary and was removed.)
+//
+// A wave instruction writes 1 KiB = 8 consecutive LDS rows, lane l to (row l>>3, 16-byte slot
+// l&7).  Rows are unpadded, so bank conflicts are avoided by an XOR swizzle: slot s of row r holds
+// K-chunk s ^ (r & 7); with it the 16-lane groups of ds_read_b128 touch 16 distinct slots.  The
+// swizzle is applied to the per-lane SOURCE address (the LDS destination of a global_load_lds is
+// not a per-lane choice) and again when fragments are read.  Rows or taps that fall outside the
+// image read a 16-byte block of zeros instead of being predicated off.
 //
 // The MFMA "A" operand is the weight tile and the "B" operand the activation tile, so a lane's
-// four accumulator registers are four consecutive output channels of one pixel: the epilogue
-// (scale, shift, residual, ReLU, bf16 convert) stores 8 contiguous bytes per tile in NHWC.
+// four accumulator registers are four consecutive output channels of one pixel.  The epilogue
+// (scale, shift, residual, ReLU, bf16 convert) stages the fp32 tile through LDS in two column
+// halves so that residual loads and output stores are whole 16-byte chunks, BN bytes contiguous
+// per pixel.
+//
+// Several "phases" (output-parity classes of a stride-2 transposed conv or of a stride-2
+// backward-data pass) run in one launch along gridDim.y, each with its own taps, weight block,
+// row grid and output offset, so small layers still fill the chip.
+#include <stdlib.h>
+
 #include "pe_igemm.h"
 
 namespace pe {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
 
-constexpr int BM = 128;
 constexpr int BK = 64;
-constexpr int LDS_ROW = 80;  // bf16 elements per LDS row
+constexpr int ROWB = 128;  // bytes per LDS row (64 bf16, unpadded)
+
+__device__ __attribute__((aligned(16))) uint32_t g_zero16[4] = {0u, 0u, 0u, 0u};
 
 __device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {
     return float_to_bf16_bits(a) | (float_to_bf16_bits(b) << 16);
 }
 
-template <int BN>
-__global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
+template <int BM, int BN>
+__global__ __launch_bounds__(256, 4) void igemm_kernel(const IgemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int TM = 4;            // 16-pixel tiles per wave (wave covers 64 pixels)
-    constexpr int TN = BN / 32;      // 16-channel tiles per wave (wave covers BN/2 channels)
-    constexpr int WROWS = BN / 32;   // weight rows staged per thread
-    constexpr int BUF = (BM + BN) * LDS_ROW;
-    uint16_t* lds = reinterpret_cast<uint16_t*>(smem);
+    constexpr int TM = BM / 32;       // 16-pixel tiles per wave (wave covers BM/2 pixels)
+    constexpr int TN = BN / 32;       // 16-channel tiles per wave (wave covers BN/2 channels)
+    constexpr int XI = BM / 32;       // activation rows staged per thread
+    constexpr int WI = BN / 32;       // weight rows staged per thread
+    constexpr int XBYTES = BM * ROWB;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -38,8 +57,18 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
     const int wave_m = wid >> 1;
     const int wave_n = wid & 1;
 
-    const long M = (long)p.B * p.Ho * p.Wo;
+    // ---- phase (uniform)
+    const int ph = blockIdx.y;
+    const int Ho = p.ph_Ho[ph], Wo = p.ph_Wo[ph];
+    const int T = p.ph_T[ph];
+    const int t0 = p.ph_t0[ph];
+    const int ooy = p.ph_ooy[ph], oox = p.ph_oox[ph];
+    const uint16_t* wbase = p.w + p.ph_woff[ph];
+
+    const int HoWo = Ho * Wo;
+    const long M = (long)p.B * HoWo;
     const int ntn = (p.N + BN - 1) / BN;
+    const long ntiles = ((M + BM - 1) / BM) * ntn;
 
     // XCD-aware tile order: workgroups that share an XCD (ids congruent mod 8) take a
     // contiguous run of tiles, so the n-tiles of one pixel panel reuse that XCD's L2.
@@ -50,24 +79,25 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
         const int xcd = bid & 7, loc = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
     }
+    if (bid >= ntiles) return;  // uniform: phases may have fewer tiles than the grid
     const int tile_m = bid / ntn;
     const int tile_n = bid - tile_m * ntn;
     const long m0 = (long)tile_m * BM;
     const int n0 = tile_n * BN;
 
-    // ---- staging assignment: thread owns 16-byte chunk `cc` of rows r0 + 32*i
-    const int cc = tid & 7;
+    // ---- staging: wave w, instruction i covers rows 32*i + 8*w .. +7; lane l -> row +(l>>3),
+    // slot l&7, which must receive K-chunk (l&7) ^ (row&7) = (l&7) ^ ((l>>3)&7)
     const int r0 = tid >> 3;
-    const int HoWo = p.Ho * p.Wo;
-    int iy0[4], ix0[4], pixbase[4];
+    const int cc = (lane & 7) ^ ((lane >> 3) & 7);
+    int iy0[XI], ix0[XI], pixbase[XI];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < XI; ++i) {
         const long m = m0 + r0 + 32 * i;
         if (m < M) {
             const int b = (int)(m / HoWo);
             const int rem = (int)(m - (long)b * HoWo);
-            const int oy = rem / p.Wo;
-            const int ox = rem - oy * p.Wo;
+            const int oy = rem / Wo;
+            const int ox = rem - oy * Wo;
             iy0[i] = oy * p.sy;
             ix0[i] = ox * p.sx;
             pixbase[i] = b * p.Hi * p.Wi;
@@ -77,302 +107,9 @@ __global__ __launch_bounds__(256, 2) void igemm_kernel(const IgemmParams p) {
             pixbase[i] = 0;
         }
     }
-    const int kc = p.Cin / BK;          // K steps per tap
-    const int KT = p.T * kc;            // K steps in total
-    const long ktot = p.wk_row;         // weight row length
-
-    uint4 xr[4], wr[WROWS];
-    int tap = 0, cstep = 0;  // position of the NEXT tile to load
-
-    auto load_tile = [&](int kt) {
-        const int dy = p.tap_dy[tap];
-        const int dx = p.tap_dx[tap];
-        const int coff = cstep * BK + cc * 8;
-        const long wk = (long)p.tap_slot[tap] * p.Cin + coff;  // K offset inside a weight row
-        const int xextra = coff >> p.cshift;
-        const int ch = coff & p.cmask;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int iy = iy0[i] + dy;
-            const int ix = ix0[i] + dx + xextra;
-            const bool ok = (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
-            const long off = (long)(pixbase[i] + iy * p.Wi + ix) * p.Cx + ch;
-            xr[i] = ok ? *reinterpret_cast<const uint4*>(p.x + off) : make_uint4(0, 0, 0, 0);
-        }
-#pragma unroll
-        for (int i = 0; i < WROWS; ++i) {
-            const int n = n0 + r0 + 32 * i;
-            const long off = (long)n * ktot + wk;
-            wr[i] = (n < p.N) ? *reinterpret_cast<const uint4*>(p.w + off) : make_uint4(0, 0, 0, 0);
-        }
-        if (++cstep == kc) {
-            cstep = 0;
-            ++tap;
-        }
-    };
-    auto store_tile = [&](int buf) {
-        uint16_t* xs = lds + buf * BUF;
-        uint16_t* ws = xs + BM * LDS_ROW;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            *reinterpret_cast<uint4*>(xs + (r0 + 32 * i) * LDS_ROW + cc * 8) = xr[i];
-#pragma unroll
-        for (int i = 0; i < WROWS; ++i)
-            *reinterpret_cast<uint4*>(ws + (r0 + 32 * i) * LDS_ROW + cc * 8) = wr[i];
-    };
-
-    f32x4 acc[TN][TM];
-#pragma unroll
-    for (int a = 0; a < TN; ++a)
-#pragma unroll
-        for (int b = 0; b < TM; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    const int lr = lane & 15;
-    const int lk = (lane >> 4) * 8;
-
-    load_tile(0);
-    store_tile(0);
-    __syncthreads();
-    for (int kt = 0; kt < KT; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < KT) load_tile(kt + 1);
-        const uint16_t* xs = lds + buf * BUF + (wave_m * 64) * LDS_ROW;
-        const uint16_t* ws = lds + buf * BUF + BM * LDS_ROW + (wave_n * (BN / 2)) * LDS_ROW;
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            bf16x8 af[TN], bfr[TM];
-#pragma unroll
-            for (int a = 0; a < TN; ++a)
-                af[a] = *reinterpret_cast<const bf16x8*>(ws + (a * 16 + lr) * LDS_ROW + kk * 32 + lk);
-#pragma unroll
-            for (int b = 0; b < TM; ++b)
-                bfr[b] = *reinterpret_cast<const bf16x8*>(xs + (b * 16 + lr) * LDS_ROW + kk * 32 + lk);
-#pragma unroll
-            for (int a = 0; a < TN; ++a)
-#pragma unroll
-                for (int b = 0; b < TM; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bfr[b], acc[a][b], 0, 0, 0);
-        }
-        if (kt + 1 < KT) store_tile(buf ^ 1);
-        __syncthreads();
-    }
-
-    // ---- epilogue
-    const bool identity = (p.osy == 1 && p.osx == 1 && p.ooy == 0 && p.oox == 0 &&
-                           p.OH == p.Ho && p.OW == p.Wo);
-    const int OHW = p.OH * p.OW;
-    const int nq = (lane >> 4) * 4;
-
-    // Fast path (bf16 NHWC, channel count a multiple of 8): the scaled fp32 tile goes through
-    // LDS (free after the K loop) so that global traffic is whole 16-byte chunks, 256 B (BN=128)
-    // contiguous per pixel: residual loads and output stores become full-line accesses.
-    // Row pitch BN + 4 floats keeps the 8-lane groups of ds_write_b128 on distinct banks.
-    if (p.out_mode == 0 && (p.N & 7) == 0 && (p.ldc & 7) == 0) {
-        constexpr int CP = BN + 4;
-        float* cs = reinterpret_cast<float*>(smem);
-#pragma unroll
-        for (int a = 0; a < TN; ++a) {
-            const int col = wave_n * (BN / 2) + a * 16 + nq;
-            const int n = n0 + col;
-            f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
-            if (n < p.N) {
-                if (p.scale) sc = *reinterpret_cast<const f32x4*>(p.scale + n);
-                if (p.shift) sh = *reinterpret_cast<const f32x4*>(p.shift + n);
-            }
-#pragma unroll
-            for (int b = 0; b < TM; ++b) {
-                const int pr = wave_m * 64 + b * 16 + lr;
-                *reinterpret_cast<f32x4*>(cs + pr * CP + col) = acc[a][b] * sc + sh;
-            }
-        }
-        __syncthreads();
-        constexpr int CPR = BN / 8;       // 16-byte output chunks per pixel row
-        constexpr int RPP = 256 / CPR;    // pixel rows per pass
-        const int chunk = tid % CPR;
-        const int prow = tid / CPR;
-        const int n = n0 + chunk * 8;
-        if (n < p.N) {
-#pragma unroll
-            for (int pass = 0; pass < BM / RPP; ++pass) {
-                const int pr = prow + pass * RPP;
-                const long m = m0 + pr;
-                if (m >= M) break;
-                long opix = m;
-                if (!identity) {
-                    const int bb = (int)(m / HoWo);
-                    const int rem = (int)(m - (long)bb * HoWo);
-                    const int oy = rem / p.Wo;
-                    const int ox = rem - oy * p.Wo;
-                    opix = (long)bb * OHW + (oy * p.osy + p.ooy) * p.OW + ox * p.osx + p.oox;
-                }
-                const f32x4 v0 = *reinterpret_cast<const f32x4*>(cs + pr * CP + chunk * 8);
-                const f32x4 v1 = *reinterpret_cast<const f32x4*>(cs + pr * CP + chunk * 8 + 4);
-                float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-                if (p.res) {
-                    const uint4 rv = *reinterpret_cast<const uint4*>(p.res + opix * p.ldc + n);
-                    const uint32_t u[4] = {rv.x, rv.y, rv.z, rv.w};
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        v[2 * i] += bf16_bits_to_float(u[i] & 0xffffu);
-                        v[2 * i + 1] += bf16_bits_to_float(u[i] >> 16);
-                    }
-                }
-                if (p.relu) {
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) v[i] = fmaxf(v[i], 0.0f);
-                }
-                uint4 o;
-                o.x = pack_bf16x2(v[0], v[1]);
-                o.y = pack_bf16x2(v[2], v[3]);
-                o.z = pack_bf16x2(v[4], v[5]);
-                o.w = pack_bf16x2(v[6], v[7]);
-                *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(p.y) + opix * p.ldc + n) = o;
-            }
-        }
-        return;
-    }
-
-#pragma unroll
-    for (int b = 0; b < TM; ++b) {
-        const long m = m0 + wave_m * 64 + b * 16 + lr;
-        if (m >= M) continue;
-        long opix;
-        int ob = 0, opl = 0;  // image index and pixel within the image (f32 NCHW mode)
-        if (identity && p.out_mode == 0) {
-            opix = m;
-        } else {
-            const int bb = (int)(m / HoWo);
-            const int rem = (int)(m - (long)bb * HoWo);
-            const int oy = rem / p.Wo;
-            const int ox = rem - oy * p.Wo;
-            opl = (oy * p.osy + p.ooy) * p.OW + ox * p.osx + p.oox;
-            ob = bb;
-            opix = (long)bb * OHW + opl;
-        }
-#pragma unroll
-        for (int a = 0; a < TN; ++a) {
-            const int n = n0 + wave_n * (BN / 2) + a * 16 + nq;
-            if (n >= p.N) continue;
-            float v[4] = {acc[a][b].x, acc[a][b].y, acc[a][b].z, acc[a][b].w};
-            const bool full = (n + 3 < p.N);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if (full || n + j < p.N) {
-                    const float sc = p.scale ? p.scale[n + j] : 1.0f;
-                    const float sh = p.shift ? p.shift[n + j] : 0.0f;
-                    v[j] = v[j] * sc + sh;
-                }
-            }
-            if (p.out_mode == 0) {
-                uint16_t* dst = reinterpret_cast<uint16_t*>(p.y) + opix * p.ldc + n;
-                if (full) {
-                    if (p.res) {
-                        const uint2 rv = *reinterpret_cast<const uint2*>(p.res + opix * p.ldc + n);
-                        v[0] += bf16_bits_to_float(rv.x & 0xffffu);
-                        v[1] += bf16_bits_to_float(rv.x >> 16);
-                        v[2] += bf16_bits_to_float(rv.y & 0xffffu);
-                        v[3] += bf16_bits_to_float(rv.y >> 16);
-                    }
-                    if (p.relu) {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.0f);
-                    }
-                    uint2 o;
-                    o.x = pack_bf16x2(v[0], v[1]);
-                    o.y = pack_bf16x2(v[2], v[3]);
-                    *reinterpret_cast<uint2*>(dst) = o;
-                } else {
-                    for (int j = 0; j < 4 && n + j < p.N; ++j) {
-                        float t = v[j];
-                        if (p.res) t += bf16_bits_to_float(p.res[opix * p.ldc + n + j]);
-                        if (p.relu) t = fmaxf(t, 0.0f);
-                        dst[j] = (uint16_t)float_to_bf16_bits(t);
-                    }
-                }
-            } else {
-                float* y32 = reinterpret_cast<float*>(p.y);
-                for (int j = 0; j < 4 && n + j < p.N; ++j) {
-                    float t = v[j];
-                    if (p.relu) t = fmaxf(t, 0.0f);
-                    y32[((long)ob * p.N + n + j) * OHW + opl] = t;
-                }
-            }
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// Direct-to-LDS variant (the default).  Tiles go global -> LDS with global_load_lds_dwordx4
-// (16 B per lane, no VGPR staging, no ds_write pass); one LDS buffer of 128-byte rows, two
-// barriers per K step, and 3-4 workgroups per CU so that other workgroups' MFMAs cover a
-// workgroup's load latency.  A wave instruction writes 1 KiB = 8 consecutive rows, lane l to
-// (row l>>3, 16-byte slot l&7); LDS rows are unpadded, so bank conflicts are avoided by an XOR
-// swizzle: slot s of row r holds K-chunk s ^ (r & 7).  The swizzle is applied to the per-lane
-// SOURCE address (the LDS destination of a global_load_lds is not a per-lane choice) and again
-// when fragments are read.  Out-of-range rows / taps read a 16-byte block of zeros instead.
-// The epilogue stages the fp32 tile through LDS in two column halves (<= 35 KB) so stores and
-// residual loads are whole lines.
-// ---------------------------------------------------------------------------------------------
-__device__ __attribute__((aligned(16))) uint32_t g_zero16[4] = {0u, 0u, 0u, 0u};
-
-typedef __attribute__((address_space(1))) const void* gptr_t;
-typedef __attribute__((address_space(3))) void* lptr_t;
-
-template <int BN>
-__global__ __launch_bounds__(256, 3) void igemm_glds_kernel(const IgemmParams p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int TM = 4;
-    constexpr int TN = BN / 32;
-    constexpr int WROWS = BN / 32;
-    constexpr int ROWB = 128;                 // bytes per LDS row (64 bf16, unpadded)
-    constexpr int XBYTES = BM * ROWB;
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wid = tid >> 6;
-    const int wave_m = wid >> 1;
-    const int wave_n = wid & 1;
-
-    const long M = (long)p.B * p.Ho * p.Wo;
-    const int ntn = (p.N + BN - 1) / BN;
-    int bid = blockIdx.x;
-    {
-        const int nwg = gridDim.x;
-        const int q = nwg >> 3, r = nwg & 7;
-        const int xcd = bid & 7, loc = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
-    }
-    const int tile_m = bid / ntn;
-    const int tile_n = bid - tile_m * ntn;
-    const long m0 = (long)tile_m * BM;
-    const int n0 = tile_n * BN;
-
-    // staging: wave w, instruction i covers rows 32*i + 8*w .. +7; lane l -> row +(l>>3), slot l&7,
-    // which must receive K-chunk (l&7) ^ (row&7) = (l&7) ^ ((l>>3)&7)
-    const int r0 = tid >> 3;                              // = 8*w + (l>>3)
-    const int cc = (lane & 7) ^ ((lane >> 3) & 7);        // logical K-chunk this lane fetches
-    const int HoWo = p.Ho * p.Wo;
-    int iy0[4], ix0[4], pixbase[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const long m = m0 + r0 + 32 * i;
-        if (m < M) {
-            const int b = (int)(m / HoWo);
-            const int rem = (int)(m - (long)b * HoWo);
-            const int oy = rem / p.Wo;
-            const int ox = rem - oy * p.Wo;
-            iy0[i] = oy * p.sy;
-            ix0[i] = ox * p.sx;
-            pixbase[i] = b * p.Hi * p.Wi;
-        } else {
-            iy0[i] = -(1 << 20);
-            ix0[i] = 0;
-            pixbase[i] = 0;
-        }
-    }
-    const int kc = p.Cin / BK;
-    const int KT = p.T * kc;
-    const long ktot = p.wk_row;
+    const int kc = p.Cin / BK;   // K steps per tap
+    const int KT = T * kc;       // K steps in total
+    const long ktot = p.wk_row;  // weight row length
     const uint16_t* zero = reinterpret_cast<const uint16_t*>(g_zero16);
 
     f32x4 acc[TN][TM];
@@ -382,22 +119,21 @@ __global__ __launch_bounds__(256, 3) void igemm_glds_kernel(const IgemmParams p)
         for (int b = 0; b < TM; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     const int lr = lane & 15;
-    const int sw = lane & 7;   // (row & 7) of every fragment row this lane reads
-    const char* xs = smem + (wave_m * 64 + lr) * ROWB;
+    const int sw = lane & 7;  // (row & 7) of every fragment row this lane reads
+    const char* xs = smem + (wave_m * (BM / 2) + lr) * ROWB;
     const char* ws = smem + XBYTES + (wave_n * (BN / 2) + lr) * ROWB;
 
-    int tap = 0, cstep = 0;
+    int tap = t0, cstep = 0;
     for (int kt = 0; kt < KT; ++kt) {
-        // ---- issue this K step's loads straight into LDS
         {
             const int dy = p.tap_dy[tap];
             const int dx = p.tap_dx[tap];
             const int coff = cstep * BK + cc * 8;
-            const long wk = (long)p.tap_slot[tap] * p.Cin + coff;
+            const long wk = (long)p.tap_slot[tap] * p.Cin + coff;  // K offset in a weight row
             const int xextra = coff >> p.cshift;
             const int ch = coff & p.cmask;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < XI; ++i) {
                 const int iy = iy0[i] + dy;
                 const int ix = ix0[i] + dx + xextra;
                 const bool ok = (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
@@ -407,9 +143,9 @@ __global__ __launch_bounds__(256, 3) void igemm_glds_kernel(const IgemmParams p)
                                                  (lptr_t)(smem + (32 * i + 8 * wid) * ROWB), 16, 0, 0);
             }
 #pragma unroll
-            for (int i = 0; i < WROWS; ++i) {
+            for (int i = 0; i < WI; ++i) {
                 const int n = n0 + r0 + 32 * i;
-                const uint16_t* src = (n < p.N) ? p.w + ((long)n * ktot + wk) : zero;
+                const uint16_t* src = (n < p.N) ? wbase + ((long)n * ktot + wk) : zero;
                 __builtin_amdgcn_global_load_lds(
                     (gptr_t)src, (lptr_t)(smem + XBYTES + (32 * i + 8 * wid) * ROWB), 16, 0, 0);
             }
@@ -418,7 +154,7 @@ __global__ __launch_bounds__(256, 3) void igemm_glds_kernel(const IgemmParams p)
                 ++tap;
             }
         }
-        __syncthreads();   // the compiler drains vmcnt before this barrier: tile is in LDS
+        __syncthreads();  // the compiler drains vmcnt before this barrier: the tile is in LDS
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             bf16x8 af[TN], bfr[TM];
@@ -435,20 +171,21 @@ __global__ __launch_bounds__(256, 3) void igemm_glds_kernel(const IgemmParams p)
                 for (int b = 0; b < TM; ++b)
                     acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bfr[b], acc[a][b], 0, 0, 0);
         }
-        __syncthreads();   // everyone is done reading before the next K step overwrites the tile
+        __syncthreads();  // everyone has read the tile before the next K step overwrites it
     }
 
     // ---- epilogue
-    const bool identity = (p.osy == 1 && p.osx == 1 && p.ooy == 0 && p.oox == 0 &&
-                           p.OH == p.Ho && p.OW == p.Wo);
+    const bool identity = (p.osy == 1 && p.osx == 1 && ooy == 0 && oox == 0 && p.OH == Ho &&
+                           p.OW == Wo);
     const int OHW = p.OH * p.OW;
     const int nq = (lane >> 4) * 4;
 
     if (p.out_mode == 0 && (p.N & 7) == 0 && (p.ldc & 7) == 0) {
-        constexpr int HALF = BN / 2;       // columns staged per pass (one wave_n half)
-        constexpr int CP = HALF + 4;       // float pitch: 8-lane ds_write_b128 groups hit distinct banks
-        constexpr int CPR = HALF / 8;      // 16-byte output chunks per pixel row
-        constexpr int RPP = 256 / CPR;     // pixel rows per pass of the store loop
+        constexpr int HALF = BN / 2;    // columns staged per pass (one wave_n half)
+        constexpr int CP = HALF + 4;    // float pitch: 8-lane ds_write_b128 groups hit distinct banks
+        constexpr int CPR = HALF / 8;   // 16-byte output chunks per pixel row
+        constexpr int RPP = 256 / CPR;  // pixel rows per pass of the store loop
+        constexpr int NPASS = (BM + RPP - 1) / RPP;
         float* cs = reinterpret_cast<float*>(smem);
         const int chunk = tid % CPR;
         const int prow = tid / CPR;
@@ -466,7 +203,7 @@ __global__ __launch_bounds__(256, 3) void igemm_glds_kernel(const IgemmParams p)
                     }
 #pragma unroll
                     for (int b = 0; b < TM; ++b) {
-                        const int pr = wave_m * 64 + b * 16 + lr;
+                        const int pr = wave_m * (BM / 2) + b * 16 + lr;
                         *reinterpret_cast<f32x4*>(cs + pr * CP + col) = acc[a][b] * sc + sh;
                     }
                 }
@@ -475,17 +212,17 @@ __global__ __launch_bounds__(256, 3) void igemm_glds_kernel(const IgemmParams p)
             const int n = n0 + half * HALF + chunk * 8;
             if (n < p.N) {
 #pragma unroll
-                for (int pass = 0; pass < BM / RPP; ++pass) {
+                for (int pass = 0; pass < NPASS; ++pass) {
                     const int pr = prow + pass * RPP;
                     const long m = m0 + pr;
-                    if (m >= M) break;
+                    if (pr >= BM || m >= M) break;
                     long opix = m;
                     if (!identity) {
                         const int bb = (int)(m / HoWo);
                         const int rem = (int)(m - (long)bb * HoWo);
-                        const int oy = rem / p.Wo;
-                        const int ox = rem - oy * p.Wo;
-                        opix = (long)bb * OHW + (oy * p.osy + p.ooy) * p.OW + ox * p.osx + p.oox;
+                        const int oy = rem / Wo;
+                        const int ox = rem - oy * Wo;
+                        opix = (long)bb * OHW + (oy * p.osy + ooy) * p.OW + ox * p.osx + oox;
                     }
                     const f32x4 v0 = *reinterpret_cast<const f32x4*>(cs + pr * CP + chunk * 8);
                     const f32x4 v1 = *reinterpret_cast<const f32x4*>(cs + pr * CP + chunk * 8 + 4);
@@ -519,13 +256,13 @@ __global__ __launch_bounds__(256, 3) void igemm_glds_kernel(const IgemmParams p)
     // general path: channel counts that are not multiples of 8, float32 NCHW output
 #pragma unroll
     for (int b = 0; b < TM; ++b) {
-        const long m = m0 + wave_m * 64 + b * 16 + lr;
+        const long m = m0 + wave_m * (BM / 2) + b * 16 + lr;
         if (m >= M) continue;
         const int bb = (int)(m / HoWo);
         const int rem = (int)(m - (long)bb * HoWo);
-        const int oy = rem / p.Wo;
-        const int ox = rem - oy * p.Wo;
-        const int opl = (oy * p.osy + p.ooy) * p.OW + ox * p.osx + p.oox;
+        const int oy = rem / Wo;
+        const int ox = rem - oy * Wo;
+        const int opl = (oy * p.osy + ooy) * p.OW + ox * p.osx + oox;
         const long opix = (long)bb * OHW + opl;
 #pragma unroll
         for (int a = 0; a < TN; ++a) {
@@ -546,66 +283,65 @@ __global__ __launch_bounds__(256, 3) void igemm_glds_kernel(const IgemmParams p)
     }
 }
 
-static bool use_regstage() {
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("PE_IGEMM_REGSTAGE");
-        v = (e && e[0] == '1') ? 1 : 0;
-    }
-    return v == 1;
+template <int BM, int BN>
+static constexpr size_t lds_bytes() {
+    const size_t ktile = (size_t)(BM + BN) * ROWB;
+    const size_t etile = (size_t)BM * (BN / 2 + 4) * sizeof(float);
+    return ktile > etile ? ktile : etile;
 }
 
 int32_t igemm_launch(const IgemmParams& pin, hipStream_t st, const char* what) {
     IgemmParams p = pin;
     if (p.wk_row == 0) p.wk_row = p.T * p.Cin;
+    if (p.nphase <= 0) {  // single phase described by the scalar fields
+        p.nphase = 1;
+        p.ph_t0[0] = 0;
+        p.ph_T[0] = (int16_t)p.T;
+        p.ph_ooy[0] = (int16_t)p.ooy;
+        p.ph_oox[0] = (int16_t)p.oox;
+        p.ph_Ho[0] = p.Ho;
+        p.ph_Wo[0] = p.Wo;
+        p.ph_woff[0] = 0;
+    }
     PE_REQUIRE(p.x && p.w && p.y, PE_E_INVALID, "%s: NULL tensor pointer", what);
-    PE_REQUIRE(p.B > 0 && p.Hi > 0 && p.Wi > 0 && p.Ho > 0 && p.Wo > 0 && p.N > 0, PE_E_INVALID,
+    PE_REQUIRE(p.B > 0 && p.Hi > 0 && p.Wi > 0 && p.N > 0 && p.nphase <= kMaxPhases, PE_E_INVALID,
                "%s: sizes must be positive", what);
     PE_REQUIRE(p.Cin > 0 && p.Cin % BK == 0, PE_E_UNSUPPORTED,
                "%s: K per tap (%d) must be a multiple of %d", what, p.Cin, BK);
     PE_REQUIRE(p.Cx % 8 == 0, PE_E_UNSUPPORTED, "%s: channels per pixel (%d) must be a multiple of 8",
                what, p.Cx);
-    PE_REQUIRE(p.T >= 1 && p.T <= kMaxTaps, PE_E_UNSUPPORTED, "%s: %d taps (max %d)", what, p.T,
-               kMaxTaps);
     PE_REQUIRE(aligned(p.x, 16) && aligned(p.w, 16) && aligned(p.y, 16) && aligned(p.res, 16) &&
                    aligned(p.scale, 16) && aligned(p.shift, 16),
                PE_E_INVALID, "%s: tensors must be 16-byte aligned", what);
     PE_REQUIRE(p.out_mode == 1 || p.ldc % 4 == 0, PE_E_UNSUPPORTED,
                "%s: output channel pitch must be a multiple of 4", what);
-    const long M = (long)p.B * p.Ho * p.Wo;
-    PE_REQUIRE((long)p.B * p.Hi * p.Wi < 0x7fffffffL && M < 0x7fffffffL &&
+    long maxM = 0;
+    for (int i = 0; i < p.nphase; ++i) {
+        PE_REQUIRE(p.ph_Ho[i] > 0 && p.ph_Wo[i] > 0 && p.ph_T[i] >= 1 &&
+                       p.ph_t0[i] + p.ph_T[i] <= kMaxTaps,
+                   PE_E_INVALID, "%s: bad phase %d", what, i);
+        const long M = (long)p.B * p.ph_Ho[i] * p.ph_Wo[i];
+        if (M > maxM) maxM = M;
+    }
+    PE_REQUIRE((long)p.B * p.Hi * p.Wi < 0x7fffffffL && maxM < 0x7fffffffL &&
                    (long)p.B * p.OH * p.OW < 0x7fffffffL,
                PE_E_UNSUPPORTED, "%s: pixel count does not fit int32", what);
-    const long ntm = (M + BM - 1) / BM;
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_kernel<128>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  2 * (BM + 128) * LDS_ROW * 2);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(igemm_kernel<64>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  2 * (BM + 64) * LDS_ROW * 2);
-        attr_set = true;
-    }
-    if (use_regstage()) {  // register-staged variant, kept for A/B timing in one binary
-        if (p.N > 64) {
-            const long ntn = (p.N + 127) / 128;
-            const size_t lds = 2 * (BM + 128) * LDS_ROW * sizeof(uint16_t);
-            igemm_kernel<128><<<(unsigned)(ntm * ntn), 256, lds, st>>>(p);
-        } else {
-            const size_t lds = 2 * (BM + 64) * LDS_ROW * sizeof(uint16_t);
-            igemm_kernel<64><<<(unsigned)ntm, 256, lds, st>>>(p);
-        }
-        return check_launch(what);
-    }
-    if (p.N > 64) {
-        const long ntn = (p.N + 127) / 128;
-        const size_t lds = BM * (64 + 4) * sizeof(float);          // epilogue half tile > K tile
-        igemm_glds_kernel<128><<<(unsigned)(ntm * ntn), 256, lds, st>>>(p);
-    } else {
-        const size_t lds = (BM + 64) * 128;                         // K tile > epilogue half tile
-        igemm_glds_kernel<64><<<(unsigned)ntm, 256, lds, st>>>(p);
-    }
+
+    // tile choice: 128-pixel tiles unless they leave the chip under-filled
+    const int bn = p.N > 64 ? 128 : 64;
+    const long ntn = (p.N + bn - 1) / bn;
+    const long wg128 = ((maxM + 127) / 128) * ntn * p.nphase;
+    const int bm = (wg128 < 768 && maxM > 64) ? 64 : 128;
+    const long ntm = (maxM + bm - 1) / bm;
+    const dim3 grid((unsigned)(ntm * ntn), (unsigned)p.nphase);
+    if (bm == 128 && bn == 128)
+        igemm_kernel<128, 128><<<grid, 256, lds_bytes<128, 128>(), st>>>(p);
+    else if (bm == 128)
+        igemm_kernel<128, 64><<<grid, 256, lds_bytes<128, 64>(), st>>>(p);
+    else if (bn == 128)
+        igemm_kernel<64, 128><<<grid, 256, lds_bytes<64, 128>(), st>>>(p);
+    else
+        igemm_kernel<64, 64><<<grid, 256, lds_bytes<64, 64>(), st>>>(p);
     return check_launch(what);
 }
 
