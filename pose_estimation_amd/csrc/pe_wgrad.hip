@@ -2,17 +2,23 @@
 //
 //   dW[n][tap*Cin + c] += sum_m dY[opix(m)][n] * X[ipix(m, tap)][c]
 //
-// The reduction runs over pixels (m), which is the strided axis of both NHWC operands, so the
-// tiles are staged row-major [m][channels] (16-byte coalesced loads) and the MFMA fragments are
-// fetched with the transposing LDS read ds_read_b64_tr_b16: a 16-lane group reads a 4-row x
-// 16-column block and each lane receives one column, i.e. four consecutive m of one channel.
-// Two such reads make the 8-deep K fragment of mfma_f32_16x16x32_bf16; the m order inside a
-// fragment is (4g+j, 16+4g+j) for lane group g, identical for both operands, which also puts
-// the eight rows a 32-lane half touches on disjoint banks (row pitch = 8 dwords mod 64).
+// The reduction runs over pixels (m), the strided axis of both NHWC operands, so tiles are
+// staged row-major [m][channels] and the MFMA fragments are fetched with the transposing LDS
+// read ds_read_b64_tr_b16: a 16-lane group reads a 4-row x 16-column block and each lane
+// receives one column, i.e. four consecutive m of one channel.  Two such reads make the 8-deep
+// K fragment of mfma_f32_16x16x32_bf16; the m order inside a fragment is (4g+j, 16+4g+j) for
+// lane group g, identical for both operands.
 //
-// Workgroup tile: 128 (n) x 128 (tap-channel columns), K step 64 pixels, split over pixels
-// across gridDim.y; partial tiles are added to dW with fp32 atomics from an LDS-staged,
-// 256-byte-contiguous layout (the caller zeroes dW).
+// Workgroup tile: 128 (n) x 128 (tap-channel columns), K step 64 pixels.  Both tiles go
+// global -> LDS with global_load_lds_dwordx4 into one buffer of unpadded 256-byte rows (a wave
+// instruction writes 4 rows); 16-byte slot s of row r holds channel chunk s ^ (2*(r&7)), which
+// puts the eight rows a 32-lane half of a transposing read touches on disjoint banks.  The
+// swizzle is applied to the per-lane source address and again on the read.  Pixels outside
+// the image or past the end of the split read a 16-byte block of zeros.  128 VGPRs and
+// <= 34 KB of LDS: four workgroups per CU cover each other's load latency.
+//
+// The pixel range is split across gridDim.y; partial tiles are added to dW with fp32 atomics
+// from an LDS-staged layout in which a wave adds 256 contiguous bytes (the caller zeroes dW).
 #include "pe_common.h"
 #include "pe_wgrad.h"
 
@@ -21,32 +27,47 @@ namespace pe {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+typedef __attribute__((address_space(3))) s16x4* lds_s16x4_t;
 
-constexpr int WG_BK = 64;       // pixels per K step
-constexpr int WG_PITCH = 144;   // bf16 elements per LDS row (128 + 16): 288 B = 72 dwords = 8*9
+constexpr int WG_BK = 64;      // pixels per K step
+constexpr int WG_ROWB = 256;   // bytes per LDS row (128 bf16, unpadded)
+constexpr int WG_TILE = WG_BK * WG_ROWB;
 
-__device__ __forceinline__ bf16x8 tr_frag(const uint16_t* lds_tile, int row_base, int col) {
-    // lds_tile: [64][WG_PITCH]; returns the 8 K values of column `col` for this lane's group.
-    typedef __attribute__((address_space(3))) s16x4* lds_ptr;
-    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-        (lds_ptr)(lds_tile + row_base * WG_PITCH + col));
-    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-        (lds_ptr)(lds_tile + (row_base + 16) * WG_PITCH + col));
+__device__ __attribute__((aligned(16))) uint32_t g_wzero16[4] = {0u, 0u, 0u, 0u};
+
+// q = m / d, r = m % d for 0 <= m < 2^31 and quotients far below 2^20 (float reciprocal + fix-up)
+__device__ __forceinline__ void fast_divmod(int m, int d, float inv_d, int& q, int& r) {
+    q = (int)((float)m * inv_d);
+    r = m - q * d;
+    if (r < 0) {
+        --q;
+        r += d;
+    } else if (r >= d) {
+        ++q;
+        r -= d;
+    }
+}
+
+__device__ __forceinline__ bf16x8 tr_frag(const char* tile, int off_lo) {
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)(tile + off_lo));
+    const s16x4 hi =
+        __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)(tile + off_lo + 16 * WG_ROWB));
     s16x8 v = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
     return __builtin_bit_cast(bf16x8, v);
 }
 
-__global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
+__global__ __launch_bounds__(256, 4) void wgrad_kernel(const WgradParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    uint16_t* lds = reinterpret_cast<uint16_t*>(smem);
-    constexpr int TILE = WG_BK * WG_PITCH;   // one operand tile
-    constexpr int BUF = 2 * TILE;            // dY tile + X tile
+    char* ytile = smem;
+    char* xtile = smem + WG_TILE;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wid = tid >> 6;
-    const int wave_c = wid >> 1;   // column half of the output tile
-    const int wave_n = wid & 1;    // n half
+    const int wave_c = wid >> 1;  // column half of the output tile
+    const int wave_n = wid & 1;   // n half
 
     const int ktot = p.T * p.Cin;
     const int ntn = (p.N + 127) / 128;
@@ -60,12 +81,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
     long me = ms + p.m_per_split;
     if (me > M) me = M;
 
-    // staging: thread owns 16-byte chunk `ch16` (8 channels) of rows (tid>>4) + 16*i
-    const int ch16 = tid & 15;
+    // staging: wave w, instruction i covers rows 16*i + 4*w .. +3; lane l -> row +(l>>4), slot
+    // l&15, which must receive channel chunk (l&15) ^ (2*(row&7)); row&7 == (tid>>4)&7
     const int rr = tid >> 4;
-    const int nn = n0 + ch16 * 8;
+    const int ls = (tid & 15) ^ (2 * (rr & 7));
+    const int nn = n0 + ls * 8;
     const bool n_ok = nn < p.N;
-    const int col = c0 + ch16 * 8;
+    const int col = c0 + ls * 8;
     const bool c_ok = col < ktot;
     int tdy = 0, tdx = 0, xch = 0;
     if (c_ok) {
@@ -77,106 +99,100 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradParams p) {
     }
     const int HoWo = p.Ho * p.Wo;
     const int OHW = p.OH * p.OW;
+    const float inv_howo = 1.0f / (float)HoWo;
+    const float inv_wo = 1.0f / (float)p.Wo;
+    const uint16_t* zero = reinterpret_cast<const uint16_t*>(g_wzero16);
 
-    uint4 gy[4], gx[4];
-    auto load_tile = [&](long mbase) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const long m = mbase + rr + 16 * i;
-            gy[i] = make_uint4(0, 0, 0, 0);
-            gx[i] = make_uint4(0, 0, 0, 0);
-            if (m < me) {
-                const int b = (int)(m / HoWo);
-                const int rem = (int)(m - (long)b * HoWo);
-                const int oy = rem / p.Wo;
-                const int ox = rem - oy * p.Wo;
-                if (n_ok) {
-                    const long opix = (long)b * OHW + (oy * p.osy + p.ooy) * p.OW + ox * p.osx + p.oox;
-                    gy[i] = *reinterpret_cast<const uint4*>(p.dy + opix * p.ldy + nn);
-                }
-                const int iy = oy * p.sy + tdy;
-                const int ix = ox * p.sx + tdx;
-                if (c_ok && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi) {
-                    const long off = ((long)b * p.Hi * p.Wi + (long)iy * p.Wi + ix) * p.Cx + xch;
-                    gx[i] = *reinterpret_cast<const uint4*>(p.x + off);
-                }
-            }
-        }
-    };
-    auto store_tile = [&](int buf) {
-        uint16_t* ys = lds + buf * BUF;
-        uint16_t* xs = ys + TILE;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            *reinterpret_cast<uint4*>(ys + (rr + 16 * i) * WG_PITCH + ch16 * 8) = gy[i];
-            *reinterpret_cast<uint4*>(xs + (rr + 16 * i) * WG_PITCH + ch16 * 8) = gx[i];
-        }
-    };
-
-    f32x4 acc[4][4];   // [column tile][n tile]
+    f32x4 acc[4][4];  // [column tile][n tile]
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // transposing-read lane geometry: lane 4q+p of a 16-lane group addresses row q, columns 4p..
+    // transposing-read geometry: lane 4q+pp of a 16-lane group g addresses row 4g+q (second
+    // read: +16), 8 bytes at column 4pp of a 16-column tile (slot 2t + (pp>>1))
     const int g = lane >> 4;
     const int q = (lane & 15) >> 2;
     const int pp = lane & 3;
-    const int row_in = 4 * g + q;     // row inside a 32-pixel K sub-step (second read: +16)
-    const int col_in = 4 * pp;        // column offset inside a 16-column tile
-
-    if (ms < me) {
-        load_tile(ms);
-        store_tile(0);
+    const int frow = 4 * g + q;
+    const int fsw = 2 * (frow & 7);
+    const int fsub = (pp >> 1);
+    const int fbyte = 8 * (pp & 1);
+    int yoff[4], xoff[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        yoff[t] = frow * WG_ROWB + (((2 * (wave_n * 4 + t) + fsub) ^ fsw) * 16) + fbyte;
+        xoff[t] = frow * WG_ROWB + (((2 * (wave_c * 4 + t) + fsub) ^ fsw) * 16) + fbyte;
     }
-    __syncthreads();
-    int it = 0;
-    for (long mb = ms; mb < me; mb += WG_BK, ++it) {
-        const int buf = it & 1;
-        const bool more = mb + WG_BK < me;
-        if (more) load_tile(mb + WG_BK);
-        const uint16_t* ys = lds + buf * BUF + wave_n * 64;
-        const uint16_t* xs = lds + buf * BUF + TILE + wave_c * 64;
+
+    for (long mb = ms; mb < me; mb += WG_BK) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const long m = mb + rr + 16 * i;
+            const uint16_t* ysrc = zero;
+            const uint16_t* xsrc = zero;
+            if (m < me) {
+                int b, rem, oy, ox;
+                fast_divmod((int)m, HoWo, inv_howo, b, rem);
+                fast_divmod(rem, p.Wo, inv_wo, oy, ox);
+                if (n_ok) {
+                    const long opix = (long)b * OHW + (oy * p.osy + p.ooy) * p.OW + ox * p.osx + p.oox;
+                    ysrc = p.dy + opix * p.ldy + nn;
+                }
+                const int iy = oy * p.sy + tdy;
+                const int ix = ox * p.sx + tdx;
+                if (c_ok && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi)
+                    xsrc = p.x + (((long)b * p.Hi * p.Wi + (long)iy * p.Wi + ix) * p.Cx + xch);
+            }
+            __builtin_amdgcn_global_load_lds((gptr_t)ysrc,
+                                             (lptr_t)(ytile + (16 * i + 4 * wid) * WG_ROWB), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)xsrc,
+                                             (lptr_t)(xtile + (16 * i + 4 * wid) * WG_ROWB), 16, 0, 0);
+        }
+        __syncthreads();  // vmcnt drained by the compiler: tiles are in LDS
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             bf16x8 fx[4], fy[4];
 #pragma unroll
-            for (int a = 0; a < 4; ++a) fx[a] = tr_frag(xs, ks * 32 + row_in, a * 16 + col_in);
+            for (int a = 0; a < 4; ++a) fx[a] = tr_frag(xtile, ks * 32 * WG_ROWB + xoff[a]);
 #pragma unroll
-            for (int b = 0; b < 4; ++b) fy[b] = tr_frag(ys, ks * 32 + row_in, b * 16 + col_in);
+            for (int b = 0; b < 4; ++b) fy[b] = tr_frag(ytile, ks * 32 * WG_ROWB + yoff[b]);
 #pragma unroll
             for (int a = 0; a < 4; ++a)
 #pragma unroll
                 for (int b = 0; b < 4; ++b)
                     acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fx[a], fy[b], acc[a][b], 0, 0, 0);
         }
-        if (more) store_tile(buf ^ 1);
-        __syncthreads();
+        __syncthreads();  // tiles consumed before the next K step overwrites them
     }
 
-    // ---- epilogue: tile -> LDS [n][col] (pitch 132 floats) -> 256-byte-contiguous atomics
+    // ---- epilogue: n halves through LDS [64 n][128 cols] (pitch 132 floats), then atomics in
+    // which a wave adds 64 consecutive floats of one row
     constexpr int CP = 132;
     float* cs = reinterpret_cast<float*>(smem);
     const int lr = lane & 15;
     const int cq = (lane >> 4) * 4;
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            const int nl = wave_n * 64 + b * 16 + lr;
-            const int cl = wave_c * 64 + a * 16 + cq;
-            *reinterpret_cast<f32x4*>(cs + nl * CP + cl) = acc[a][b];
-        }
-    __syncthreads();
     const int cl = tid & 127;
     const int colg = c0 + cl;
-    if (colg < ktot) {
-        for (int nl = tid >> 7; nl < 128; nl += 2) {
-            const int n = n0 + nl;
-            if (n >= p.Nw) break;
-            atomicAdd(p.dw + (long)n * ktot + colg, cs[nl * CP + cl]);
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        if (wave_n == half) {
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+                    *reinterpret_cast<f32x4*>(cs + (b * 16 + lr) * CP + wave_c * 64 + a * 16 + cq) =
+                        acc[a][b];
         }
+        __syncthreads();
+        if (colg < ktot) {
+            for (int nl = tid >> 7; nl < 64; nl += 2) {
+                const int n = n0 + half * 64 + nl;
+                if (n >= p.Nw) break;
+                atomicAdd(p.dw + (long)n * ktot + colg, cs[nl * CP + cl]);
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -192,11 +208,12 @@ int32_t wgrad_launch(WgradParams& p, hipStream_t st, const char* what) {
     PE_REQUIRE(aligned(p.x, 16) && aligned(p.dy, 16) && aligned(p.dw, 4), PE_E_INVALID,
                "%s: tensors must be 16-byte aligned", what);
     const long M = (long)p.B * p.Ho * p.Wo;
-    PE_REQUIRE(M < 0x7fffffffL && (long)p.B * p.OH * p.OW < 0x7fffffffL, PE_E_UNSUPPORTED,
-               "%s: pixel count does not fit int32", what);
+    PE_REQUIRE(M < 0x7fffffffL && (long)p.B * p.OH * p.OW < 0x7fffffffL &&
+                   (long)p.Ho * p.Wo < (1L << 22) && p.B < (1 << 20),
+               PE_E_UNSUPPORTED, "%s: pixel counts out of range", what);
     const long ktot = (long)p.T * p.Cin;
     const long tiles = ((p.N + 127) / 128) * ((ktot + 127) / 128);
-    long splits = (768 + tiles - 1) / tiles;
+    long splits = (1024 + tiles - 1) / tiles;
     const long max_splits = (M + 255) / 256;
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
@@ -204,13 +221,7 @@ int32_t wgrad_launch(WgradParams& p, hipStream_t st, const char* what) {
     mps = (mps + WG_BK - 1) / WG_BK * WG_BK;
     splits = (M + mps - 1) / mps;
     p.m_per_split = mps;
-    static bool attr_set = false;
-    const size_t lds = 2 * 2 * WG_BK * WG_PITCH * sizeof(uint16_t);
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
+    const size_t lds = 64 * 132 * sizeof(float);  // epilogue half tile (33.8 KB) > K tiles (32 KB)
     wgrad_kernel<<<dim3((unsigned)tiles, (unsigned)splits), 256, lds, st>>>(p);
     return check_launch(what);
 }
