@@ -218,16 +218,22 @@ int32_t pe_deconv4x4s2_bwd_data_bf16(int32_t B, int32_t H, int32_t W, int32_t Ci
                                      pe_stream_t stream);
 
 /* Backward-weight: dw (float32, same layout as the packed forward weight) += x (*) dy.
- * The caller zeroes dw; partial sums from different pixel ranges are combined with float32
- * atomics.  ldy = channels per pixel of dy (>= Cout rounded up to 8; lets a zero-padded
+ * The caller zeroes dw.  The pixel range is split over workgroups; each split writes a partial
+ * dw into `workspace` (device memory, at least pe_wgrad_workspace_bytes(elements of the
+ * largest dw passed)) and an ordered reduction folds them, so results are bit-stable from run
+ * to run.  ldy = channels per pixel of dy (>= Cout rounded up to 8; lets a zero-padded
  * gradient of a narrow layer be used). */
+size_t pe_wgrad_workspace_bytes(int64_t weight_elems);
 int32_t pe_conv2d_bwd_weight_bf16(const pe_conv_desc* d, const void* x, const void* dy,
-                                  int32_t ldy, float* dw, pe_stream_t stream);
+                                  int32_t ldy, float* dw, void* workspace,
+                                  size_t workspace_bytes, pe_stream_t stream);
 int32_t pe_deconv4x4s2_bwd_weight_bf16(int32_t B, int32_t H, int32_t W, int32_t Cin,
                                        int32_t Cout, const void* x, const void* dy,
-                                       float* dw_phases, pe_stream_t stream);
+                                       float* dw_phases, void* workspace,
+                                       size_t workspace_bytes, pe_stream_t stream);
 int32_t pe_stem7x7s2_bwd_weight_bf16(int32_t B, int32_t H2, int32_t W2, int32_t Cout,
                                      const void* x_s2d, const void* dy, float* dw,
+                                     void* workspace, size_t workspace_bytes,
                                      pe_stream_t stream);
 
 /* out[c][t0 + t][a] = in[a][t][c] (bf16), out rows are slots*apitch elements long.  Builds the

@@ -92,15 +92,19 @@ SIGNATURES = {
         c_int32,
         [c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p],
     ),
+    "pe_wgrad_workspace_bytes": (c_size_t, [c_int64]),
     "pe_conv2d_bwd_weight_bf16": (
-        c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p],
+        c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_size_t, c_void_p],
     ),
     "pe_deconv4x4s2_bwd_weight_bf16": (
         c_int32,
-        [c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p],
+        [c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p,
+         c_size_t, c_void_p],
     ),
     "pe_stem7x7s2_bwd_weight_bf16": (
-        c_int32, [c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p],
+        c_int32,
+        [c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
+         c_void_p],
     ),
     "pe_transpose_weights_bf16": (
         c_int32,

@@ -110,21 +110,16 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_bwd_kernel(const uint16_t* _
     }
 }
 
-// Loss gradient hand-over: float32 [B][K][HW] -> bf16 [B*HW][Kpad] (zero padded) and the bias
-// gradient dbias[k] += sum over pixels.
+// Loss gradient hand-over: float32 [B][K][HW] -> bf16 [B*HW][Kpad] (zero padded).
 __global__ __launch_bounds__(256) void final_grad_prepare_kernel(const float* __restrict__ g,
                                                                  long npix, int K, int HW,
                                                                  int Kpad,
-                                                                 uint16_t* __restrict__ out,
-                                                                 float* __restrict__ dbias) {
+                                                                 uint16_t* __restrict__ out) {
     // reads are coalesced along pixels (one plane per k); the [256 pixels][Kpad] tile is
     // transposed through LDS so the bf16 rows leave as whole 16-byte chunks
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    __shared__ float red[32];
     const int pitch = Kpad + 8;
     uint16_t* tile = reinterpret_cast<uint16_t*>(smem);
-    if (threadIdx.x < 32) red[threadIdx.x] = 0.0f;
-    __syncthreads();
     const long pix0 = (long)blockIdx.x * 256;
     const long pix = pix0 + threadIdx.x;
     const bool ok = pix < npix;
@@ -134,10 +129,6 @@ __global__ __launch_bounds__(256) void final_grad_prepare_kernel(const float* __
         float v = 0.0f;
         if (ok && k < K) v = g[(b * K + k) * HW + pl];
         tile[threadIdx.x * pitch + k] = (uint16_t)float_to_bf16_bits(v);
-        if (k < K && dbias) {
-            const float s = wave_sum(v);
-            if ((threadIdx.x & 63) == 0) atomicAdd(&red[k], s);
-        }
     }
     __syncthreads();
     const int cpr = Kpad / 8;  // 16-byte chunks per pixel row
@@ -148,7 +139,23 @@ __global__ __launch_bounds__(256) void final_grad_prepare_kernel(const float* __
             *reinterpret_cast<uint4*>(out + (pix0 + row) * Kpad + cc * 8) =
                 *reinterpret_cast<const uint4*>(tile + row * pitch + cc * 8);
     }
-    if (dbias && threadIdx.x < K) atomicAdd(dbias + threadIdx.x, red[threadIdx.x]);
+}
+
+// dbias[k] += sum over images and pixels of g[b][k][:], one workgroup per k, summed in a fixed
+// order (thread-strided partials, wave shuffle tree, waves in order): bit-stable.
+__global__ __launch_bounds__(256) void bias_grad_kernel(const float* __restrict__ g, int B, int K,
+                                                        int HW, float* __restrict__ dbias) {
+    __shared__ float red[4];
+    const int k = blockIdx.x;
+    float s = 0.0f;
+    for (int b = 0; b < B; ++b) {
+        const float* plane = g + ((long)b * K + k) * HW;
+        for (int i = threadIdx.x; i < HW; i += 256) s += plane[i];
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) dbias[k] += ((red[0] + red[1]) + red[2]) + red[3];
 }
 
 __global__ __launch_bounds__(256) void mul_f32_kernel(float* __restrict__ a,
@@ -282,7 +289,8 @@ extern "C" int32_t pe_deconv4x4s2_bwd_data_bf16(int32_t B, int32_t H, int32_t W,
 }
 
 extern "C" int32_t pe_conv2d_bwd_weight_bf16(const pe_conv_desc* d, const void* x, const void* dy,
-                                             int32_t ldy, float* dw, pe_stream_t stream) {
+                                             int32_t ldy, float* dw, void* workspace,
+                                             size_t workspace_bytes, pe_stream_t stream) {
     PE_REQUIRE(d != nullptr, PE_E_INVALID, "pe_conv2d_bwd_weight_bf16: NULL descriptor");
     PE_REQUIRE(d->KH > 0 && d->KW > 0 && d->KH * d->KW <= kMaxTaps, PE_E_UNSUPPORTED,
                "pe_conv2d_bwd_weight_bf16: filter %dx%d not supported", d->KH, d->KW);
@@ -318,12 +326,14 @@ extern "C" int32_t pe_conv2d_bwd_weight_bf16(const pe_conv_desc* d, const void* 
     p.OH = Ho;
     p.OW = Wo;
     p.ldy = ldy;
-    return wgrad_launch(p, as_stream(stream), "pe_conv2d_bwd_weight_bf16");
+    return wgrad_launch(p, workspace, workspace_bytes, as_stream(stream),
+                        "pe_conv2d_bwd_weight_bf16");
 }
 
 extern "C" int32_t pe_deconv4x4s2_bwd_weight_bf16(int32_t B, int32_t H, int32_t W, int32_t Cin,
                                                   int32_t Cout, const void* x, const void* dy,
-                                                  float* dw_phases, pe_stream_t stream) {
+                                                  float* dw_phases, void* workspace,
+                                                  size_t workspace_bytes, pe_stream_t stream) {
     PE_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, PE_E_INVALID,
                "pe_deconv4x4s2_bwd_weight_bf16: sizes must be positive");
     PE_REQUIRE(dw_phases != nullptr, PE_E_INVALID, "pe_deconv4x4s2_bwd_weight_bf16: NULL dw");
@@ -355,7 +365,8 @@ extern "C" int32_t pe_deconv4x4s2_bwd_weight_bf16(int32_t B, int32_t H, int32_t 
             p.ooy = py;
             p.oox = px;
             p.ldy = Cout;
-            const int32_t rc = wgrad_launch(p, as_stream(stream), "pe_deconv4x4s2_bwd_weight_bf16");
+            const int32_t rc = wgrad_launch(p, workspace, workspace_bytes, as_stream(stream),
+                                            "pe_deconv4x4s2_bwd_weight_bf16");
             if (rc != PE_OK) return rc;
         }
     return PE_OK;
@@ -363,6 +374,7 @@ extern "C" int32_t pe_deconv4x4s2_bwd_weight_bf16(int32_t B, int32_t H, int32_t 
 
 extern "C" int32_t pe_stem7x7s2_bwd_weight_bf16(int32_t B, int32_t H2, int32_t W2, int32_t Cout,
                                                 const void* x_s2d, const void* dy, float* dw,
+                                                void* workspace, size_t workspace_bytes,
                                                 pe_stream_t stream) {
     PE_REQUIRE(B > 0 && H2 > 0 && W2 > 0 && Cout > 0, PE_E_INVALID,
                "pe_stem7x7s2_bwd_weight_bf16: sizes must be positive");
@@ -390,7 +402,8 @@ extern "C" int32_t pe_stem7x7s2_bwd_weight_bf16(int32_t B, int32_t H2, int32_t W
     p.OH = H2;
     p.OW = W2;
     p.ldy = Cout;
-    return wgrad_launch(p, as_stream(stream), "pe_stem7x7s2_bwd_weight_bf16");
+    return wgrad_launch(p, workspace, workspace_bytes, as_stream(stream),
+                        "pe_stem7x7s2_bwd_weight_bf16");
 }
 
 extern "C" int32_t pe_transpose_weights_bf16(const void* in, int32_t A, int32_t T, int32_t C,
@@ -433,8 +446,15 @@ extern "C" int32_t pe_final_grad_prepare_bf16(const float* g_nchw, int32_t B, in
     const long npix = (long)B * HW;
     const size_t lds = (size_t)256 * (Kpad + 8) * sizeof(uint16_t);
     final_grad_prepare_kernel<<<(unsigned)((npix + 255) / 256), 256, lds, as_stream(stream)>>>(
-        g_nchw, npix, K, HW, Kpad, static_cast<uint16_t*>(out_nhwc), dbias);
-    return check_launch("pe_final_grad_prepare_bf16");
+        g_nchw, npix, K, HW, Kpad, static_cast<uint16_t*>(out_nhwc));
+    const int32_t rc = check_launch("pe_final_grad_prepare_bf16");
+    if (rc != PE_OK || dbias == nullptr) return rc;
+    bias_grad_kernel<<<(unsigned)K, 256, 0, as_stream(stream)>>>(g_nchw, B, K, HW, dbias);
+    return check_launch("pe_final_grad_prepare_bf16 (bias)");
+}
+
+extern "C" size_t pe_wgrad_workspace_bytes(int64_t weight_elems) {
+    return wgrad_workspace_bytes(weight_elems > 0 ? (long)weight_elems : 0);
 }
 
 extern "C" int32_t pe_mul_f32(float* a, const float* b, int64_t n, pe_stream_t stream) {

@@ -17,8 +17,9 @@
 // the image or past the end of the split read a 16-byte block of zeros.  128 VGPRs and
 // <= 34 KB of LDS: four workgroups per CU cover each other's load latency.
 //
-// The pixel range is split across gridDim.y; partial tiles are added to dW with fp32 atomics
-// from an LDS-staged layout in which a wave adds 256 contiguous bytes (the caller zeroes dW).
+// The pixel range is split across gridDim.y.  Each split stores its partial tile to a slab of
+// the workspace (LDS-staged so a wave writes 256 contiguous bytes) and wgrad_reduce_kernel adds
+// the slabs to dW in a fixed order: no float atomics, so a step repeats bit for bit.
 #include "pe_common.h"
 #include "pe_wgrad.h"
 
@@ -166,8 +167,8 @@ __global__ __launch_bounds__(256, 4) void wgrad_kernel(const WgradParams p) {
         __syncthreads();  // tiles consumed before the next K step overwrites them
     }
 
-    // ---- epilogue: n halves through LDS [64 n][128 cols] (pitch 132 floats), then atomics in
-    // which a wave adds 64 consecutive floats of one row
+    // ---- epilogue: n halves through LDS [64 n][128 cols] (pitch 132 floats), then stores in
+    // which a wave writes 64 consecutive floats of one row
     constexpr int CP = 132;
     float* cs = reinterpret_cast<float*>(smem);
     const int lr = lane & 15;
@@ -186,17 +187,65 @@ __global__ __launch_bounds__(256, 4) void wgrad_kernel(const WgradParams p) {
         }
         __syncthreads();
         if (colg < ktot) {
+            // one split: this workgroup owns the elements, add in place; several splits: each
+            // writes its own slab with plain stores and wgrad_reduce_kernel folds them in order
+            float* dst = gridDim.y == 1 ? p.dw : p.slab + (long)blockIdx.y * p.slab_stride;
             for (int nl = tid >> 7; nl < 64; nl += 2) {
                 const int n = n0 + half * 64 + nl;
                 if (n >= p.Nw) break;
-                atomicAdd(p.dw + (long)n * ktot + colg, cs[nl * CP + cl]);
+                const long e = (long)n * ktot + colg;
+                const float v = cs[nl * CP + cl];
+                dst[e] = gridDim.y == 1 ? dst[e] + v : v;
             }
         }
         __syncthreads();
     }
 }
 
-int32_t wgrad_launch(WgradParams& p, hipStream_t st, const char* what) {
+// dw[e] += sum over slabs of slab[s][e], in an order fixed by (S, SL) alone, so results repeat
+// bit for bit.  A workgroup owns 256/SL groups of four elements; split lane j adds slabs
+// j, j+SL, ... and the SL partial sums are folded in lane order through LDS.  Small weights
+// with hundreds of slabs get SL = 16 so the slab loop stays short; P must be a multiple of 4.
+template <int SL>
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, int S,
+                                                           long P, float* __restrict__ dw) {
+    constexpr int COLS = 256 / SL;
+    __shared__ f32x4 part[SL > 1 ? 256 : 1];
+    const int colt = threadIdx.x % COLS;
+    const int sl = threadIdx.x / COLS;
+    const long i = (long)blockIdx.x * COLS + colt;  // group of four elements
+    const bool ok = 4 * i < P;
+    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+    if (ok) {
+        const float* src = slab + 4 * i;
+        int s = sl;
+        for (; s + 3 * SL < S; s += 4 * SL) {
+            const f32x4 v0 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src + (long)s * P));
+            const f32x4 v1 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src + (long)(s + SL) * P));
+            const f32x4 v2 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src + (long)(s + 2 * SL) * P));
+            const f32x4 v3 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src + (long)(s + 3 * SL) * P));
+            a += v0;
+            a += v1;
+            a += v2;
+            a += v3;
+        }
+        for (; s < S; s += SL)
+            a += __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src + (long)s * P));
+    }
+    if constexpr (SL > 1) {
+        part[threadIdx.x] = a;
+        __syncthreads();
+        if (sl != 0) return;
+        for (int j = 1; j < SL; ++j) a += part[j * COLS + colt];
+    }
+    if (ok) {
+        f32x4* d = reinterpret_cast<f32x4*>(dw + 4 * i);
+        *d = *d + a;
+    }
+}
+
+int32_t wgrad_launch(WgradParams& p, void* workspace, size_t workspace_bytes, hipStream_t st,
+                     const char* what) {
     PE_REQUIRE(p.x && p.dy && p.dw, PE_E_INVALID, "%s: NULL tensor pointer", what);
     PE_REQUIRE(p.B > 0 && p.Hi > 0 && p.Wi > 0 && p.Ho > 0 && p.Wo > 0 && p.N > 0 && p.Nw > 0 &&
                    p.Nw <= p.N,
@@ -212,8 +261,9 @@ int32_t wgrad_launch(WgradParams& p, hipStream_t st, const char* what) {
                    (long)p.Ho * p.Wo < (1L << 22) && p.B < (1 << 20),
                PE_E_UNSUPPORTED, "%s: pixel counts out of range", what);
     const long ktot = (long)p.T * p.Cin;
+    const long P = (long)p.Nw * ktot;
     const long tiles = ((p.N + 127) / 128) * ((ktot + 127) / 128);
-    long splits = (1024 + tiles - 1) / tiles;
+    long splits = (kWgradTargetBlocks + tiles - 1) / tiles;
     const long max_splits = (M + 255) / 256;
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
@@ -221,9 +271,38 @@ int32_t wgrad_launch(WgradParams& p, hipStream_t st, const char* what) {
     mps = (mps + WG_BK - 1) / WG_BK * WG_BK;
     splits = (M + mps - 1) / mps;
     p.m_per_split = mps;
+    p.slab = static_cast<float*>(workspace);
+    p.slab_stride = P;
+    if (splits > 1) {
+        PE_REQUIRE(workspace != nullptr && aligned(workspace, 16) && aligned(p.dw, 16), PE_E_INVALID,
+                   "%s: workspace and dw must be 16-byte aligned and non-NULL", what);
+        PE_REQUIRE((size_t)splits * (size_t)P * sizeof(float) <= workspace_bytes, PE_E_INVALID,
+                   "%s: workspace too small (%zu bytes needed)", what,
+                   (size_t)splits * (size_t)P * sizeof(float));
+    }
     const size_t lds = 64 * 132 * sizeof(float);  // epilogue half tile (33.8 KB) > K tiles (32 KB)
     wgrad_kernel<<<dim3((unsigned)tiles, (unsigned)splits), 256, lds, st>>>(p);
+    int32_t rc = check_launch(what);
+    if (rc != PE_OK || splits == 1) return rc;
+    const long groups = P >> 2;
+    if (splits >= 64) {
+        wgrad_reduce_kernel<16><<<(unsigned)((groups + 15) / 16), 256, 0, st>>>(p.slab, (int)splits,
+                                                                              P, p.dw);
+    } else if (splits >= 8) {
+        wgrad_reduce_kernel<4><<<(unsigned)((groups + 63) / 64), 256, 0, st>>>(p.slab, (int)splits,
+                                                                             P, p.dw);
+    } else {
+        wgrad_reduce_kernel<1><<<(unsigned)((groups + 255) / 256), 256, 0, st>>>(p.slab, (int)splits,
+                                                                              P, p.dw);
+    }
     return check_launch(what);
+}
+
+size_t wgrad_workspace_bytes(long P) {
+    // splits * P <= (target/tiles + 1) * P with tiles >= P / 16384
+    const size_t by_target = (size_t)(kWgradTargetBlocks + 1) * 16384 * sizeof(float);
+    const size_t two = 2 * (size_t)P * sizeof(float);
+    return (by_target > two ? by_target : two) + (size_t)P * sizeof(float);
 }
 
 }  // namespace pe

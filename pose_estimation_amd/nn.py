@@ -216,6 +216,21 @@ def deconv4x4s2_bwd_data(dy: torch.Tensor, w_t: torch.Tensor,
     return out
 
 
+_wgrad_ws: dict = {}
+
+
+def wgrad_workspace(weight_elems: int, device) -> torch.Tensor:
+    """Scratch for the split partial sums of the backward-weight GEMM (cached per device,
+    grown on demand; calls on one stream reuse it safely)."""
+    need = lib().pe_wgrad_workspace_bytes(int(weight_elems))
+    key = str(device)
+    ws = _wgrad_ws.get(key)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(need, dtype=torch.uint8, device=device)
+        _wgrad_ws[key] = ws
+    return ws
+
+
 def conv2d_bwd_weight(x: torch.Tensor, dy: torch.Tensor, dw: torch.Tensor, k: int, stride: int,
                       pad: int, cout: Optional[int] = None) -> None:
     """dw (float32 [Cout,k,k,Cin], pre-zeroed) += weight gradient.  dy may be zero-padded to more
@@ -229,8 +244,10 @@ def conv2d_bwd_weight(x: torch.Tensor, dy: torch.Tensor, dw: torch.Tensor, k: in
         raise ValueError("dw must be contiguous float32 [Cout,k,k,Cin]")
     d = ConvDesc(B, H, W, Cin, cout, k, k, stride, pad, 0, 0)
     with torch.cuda.device(x.device):
+        ws = wgrad_workspace(dw.numel(), x.device)
         check(lib().pe_conv2d_bwd_weight_bf16(ctypes.addressof(d), x.data_ptr(), dy.data_ptr(), ldy,
-                                              dw.data_ptr(), _stream(x)))
+                                              dw.data_ptr(), ws.data_ptr(), ws.numel(),
+                                              _stream(x)))
 
 
 def deconv4x4s2_bwd_weight(x: torch.Tensor, dy: torch.Tensor, dw: torch.Tensor) -> None:
@@ -241,8 +258,10 @@ def deconv4x4s2_bwd_weight(x: torch.Tensor, dy: torch.Tensor, dw: torch.Tensor) 
     if dw.dtype != torch.float32 or dw.numel() != 16 * Cout * Cin:
         raise ValueError("dw must be float32 [4,Cout,4,Cin]")
     with torch.cuda.device(x.device):
+        ws = wgrad_workspace(dw.numel() // 4, x.device)
         check(lib().pe_deconv4x4s2_bwd_weight_bf16(B, H, W, Cin, Cout, x.data_ptr(), dy.data_ptr(),
-                                                   dw.data_ptr(), _stream(x)))
+                                                   dw.data_ptr(), ws.data_ptr(), ws.numel(),
+                                                   _stream(x)))
 
 
 def stem7x7s2_bwd_weight(x_s2d: torch.Tensor, dy: torch.Tensor, dw: torch.Tensor) -> None:
@@ -251,8 +270,10 @@ def stem7x7s2_bwd_weight(x_s2d: torch.Tensor, dy: torch.Tensor, dw: torch.Tensor
     B, H2, W2, _ = x_s2d.shape
     Cout = dy.shape[3]
     with torch.cuda.device(x_s2d.device):
+        ws = wgrad_workspace(dw.numel(), x_s2d.device)
         check(lib().pe_stem7x7s2_bwd_weight_bf16(B, H2, W2, Cout, x_s2d.data_ptr(), dy.data_ptr(),
-                                                 dw.data_ptr(), _stream(x_s2d)))
+                                                 dw.data_ptr(), ws.data_ptr(), ws.numel(),
+                                                 _stream(x_s2d)))
 
 
 def maxpool3x3s2_bwd(x: torch.Tensor, dy: torch.Tensor,

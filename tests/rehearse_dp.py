@@ -72,7 +72,7 @@ def worker(rank, world, port):
     want = torch.stack(gathered).sum(0)
     err = (net.grads.cpu() - want).abs().max().item() / (want.abs().max().item() + 1e-30)
     log(rank, f"summed gradient rel err {err:.2e}")
-    assert err < 1e-3, err   # float32 atomics reorder the two backward passes slightly
+    assert err < 1e-5, err   # the all-reduce adds rank sums in its own order
 
     for i in range(3):
         loss, _ = net.train_step(img, joints, lr=1e-3)

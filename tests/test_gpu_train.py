@@ -162,9 +162,9 @@ def test_training_reduces_the_loss_and_is_reproducible():
         losses.append(run)
     print("losses", losses[0])
     assert losses[0][-1] < 0.7 * losses[0][0]
-    # weight gradients use float32 atomics, whose order varies: the trajectory is reproducible
-    # to rounding, not bit for bit
-    assert np.allclose(losses[0], losses[1], rtol=5e-3)
+    # every reduction on the path (weight-gradient slabs, BN statistics, loss) runs in a fixed
+    # order, so the same inputs give the same trajectory bit for bit
+    assert losses[0] == losses[1]
 
 
 def test_sgd_step_and_bn_running_stats_move():
