@@ -82,6 +82,16 @@ def test_resnet50_pose_forward_reduced_resolution():
     check(*run_case((3, 4, 6, 3), B=2, H=128, W=96, seed=4))
 
 
+def test_high_resolution_384x288_gives_96x72_maps():
+    got, ref, ref32 = run_case((1, 1, 1, 1), B=1, H=384, W=288, seed=6)
+    assert got.shape == (1, 17, 96, 72)
+    check(got, ref, ref32)
+
+
+def test_resnet50_pose_forward_full_resolution():
+    check(*run_case((3, 4, 6, 3), B=1, H=256, W=192, seed=8))
+
+
 def test_predict_is_deterministic_and_batch_independent():
     net = pm.PoseResNet("cuda:0", layers=(1, 1, 1, 1))
     state = pm.init_state(net.specs, seed=9)
