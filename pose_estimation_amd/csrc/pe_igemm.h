@@ -41,6 +41,7 @@ struct IgemmParams {
     int16_t tap_dy[kMaxTaps];
     int16_t tap_dx[kMaxTaps];
     uint8_t tap_slot[kMaxTaps];  // position of each tap's Cin-block inside a weight row
+    int32_t tap_info[kMaxTaps];  // dy | dx << 8 | slot << 16, packed by igemm_launch for the kernel
     // Optional phases (gridDim.y): phase i uses taps [ph_t0[i], ph_t0[i] + ph_T[i]), the row grid
     // ph_Ho[i] x ph_Wo[i], output offset (ph_ooy[i], ph_oox[i]) and weights w + ph_woff[i].
     // nphase == 0: one phase taken from T, Ho, Wo, ooy, oox.

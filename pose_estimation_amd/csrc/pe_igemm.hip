@@ -1,11 +1,14 @@
 // Implicit-GEMM convolution kernel: bf16 MFMA 16x16x32, fp32 accumulate, direct-to-LDS tiles.
 //
-// Workgroup = 256 threads = 4 waves (2 along m x 2 along n), output tile BM (pixels: 128 or 64)
-// x BN (channels: 128 or 64), K step 64.  Tiles go global -> LDS with global_load_lds_dwordx4
-// (16 B per lane, no VGPR staging, no ds_write pass) into ONE buffer of 128-byte rows; two
-// barriers per K step; 128 VGPRs and <= 35 KB of LDS so four workgroups share a CU and their
-// MFMAs cover each other's load latency.  (A register-staged, double-buffered variant of this
-// kernel ran 25 % slower end to end in the same binary and was removed.)
+// Workgroup = WM x 2 waves (WM = 2 or 4 along pixels, 2 along channels), output tile BM pixels
+// x BN channels, K step 64; every wave owns a (BM/WM) x (BN/2) sub-tile.  Tiles go global -> LDS
+// with global_load_lds_dwordx4 (16 B per lane, no VGPR staging, no ds_write pass) into 128-byte
+// rows.  Two pipelines exist:
+//   single buffer : load, barrier, MFMA, barrier; <= 35 KB of LDS and 128 VGPRs, so four
+//                   256-thread workgroups share a CU and cover each other's load latency;
+//   double buffer : the loads of K step k+1 are in flight while step k is multiplied, one
+//                   barrier per step; the workgroup hides its own latency, which is what lets
+//                   256-pixel tiles (fewer L2 -> LDS bytes per flop) run with 1-2 workgroups per CU.
 //
 // A wave instruction writes 1 KiB = 8 consecutive LDS rows, lane l to (row l>>3, 16-byte slot
 // l&7).  Rows are unpadded, so bank conflicts are avoided by an XOR swizzle: slot s of row r holds
@@ -23,6 +26,7 @@
 // Several "phases" (output-parity classes of a stride-2 transposed conv or of a stride-2
 // backward-data pass) run in one launch along gridDim.y, each with its own taps, weight block,
 // row grid and output offset, so small layers still fill the chip.
+#include <stdio.h>
 #include <stdlib.h>
 
 #include "pe_igemm.h"
@@ -42,14 +46,34 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {
     return float_to_bf16_bits(a) | (float_to_bf16_bits(b) << 16);
 }
 
-template <int BM, int BN>
-__global__ __launch_bounds__(256, 4) void igemm_kernel(const IgemmParams p) {
+// q = m / d, r = m % d for 0 <= m < 2^31, d >= 1 and quotients below 2^20: float reciprocal
+// estimate, then one fix-up step either way (an integer division costs about 40 instructions).
+__device__ __forceinline__ void fast_divmod(int m, int d, float inv_d, int& q, int& r) {
+    q = (int)((float)m * inv_d);
+    r = m - q * d;
+    if (r < 0) {
+        --q;
+        r += d;
+    } else if (r >= d) {
+        ++q;
+        r -= d;
+    }
+}
+
+template <int BM, int BN, int WM, bool DB, bool PF, int MINB>
+__global__ __launch_bounds__(WM * 128, MINB)
+__attribute__((amdgpu_waves_per_eu(MINB * WM / 2, MINB * WM / 2))) void igemm_kernel(const IgemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int TM = BM / 32;       // 16-pixel tiles per wave (wave covers BM/2 pixels)
+    constexpr int NT = WM * 128;      // threads
+    constexpr int RPI = NT / 8;       // tile rows one staging instruction of the workgroup covers
+    constexpr int WROWS = BM / WM;    // pixels per wave
+    constexpr int TM = WROWS / 16;    // 16-pixel tiles per wave
     constexpr int TN = BN / 32;       // 16-channel tiles per wave (wave covers BN/2 channels)
-    constexpr int XI = BM / 32;       // activation rows staged per thread
-    constexpr int WI = BN / 32;       // weight rows staged per thread
+    constexpr int XI = BM / RPI;      // activation rows staged per thread
+    constexpr int WI = BN / RPI;      // weight rows staged per thread
     constexpr int XBYTES = BM * ROWB;
+    constexpr int TILEB = (BM + BN) * ROWB;
+    static_assert(XI >= 1 && WI >= 1 && TM >= 1, "tile too small for the workgroup");
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -85,19 +109,20 @@ __global__ __launch_bounds__(256, 4) void igemm_kernel(const IgemmParams p) {
     const long m0 = (long)tile_m * BM;
     const int n0 = tile_n * BN;
 
-    // ---- staging: wave w, instruction i covers rows 32*i + 8*w .. +7; lane l -> row +(l>>3),
+    // ---- staging: wave w, instruction i covers rows RPI*i + 8*w .. +7; lane l -> row +(l>>3),
     // slot l&7, which must receive K-chunk (l&7) ^ (row&7) = (l&7) ^ ((l>>3)&7)
     const int r0 = tid >> 3;
     const int cc = (lane & 7) ^ ((lane >> 3) & 7);
+    const float inv_howo = 1.0f / (float)HoWo;
+    const float inv_wo = 1.0f / (float)Wo;
     int iy0[XI], ix0[XI], pixbase[XI];
 #pragma unroll
     for (int i = 0; i < XI; ++i) {
-        const long m = m0 + r0 + 32 * i;
+        const long m = m0 + r0 + RPI * i;
         if (m < M) {
-            const int b = (int)(m / HoWo);
-            const int rem = (int)(m - (long)b * HoWo);
-            const int oy = rem / Wo;
-            const int ox = rem - oy * Wo;
+            int b, rem, oy, ox;
+            fast_divmod((int)m, HoWo, inv_howo, b, rem);
+            fast_divmod(rem, Wo, inv_wo, oy, ox);
             iy0[i] = oy * p.sy;
             ix0[i] = ox * p.sx;
             pixbase[i] = b * p.Hi * p.Wi;
@@ -120,58 +145,106 @@ __global__ __launch_bounds__(256, 4) void igemm_kernel(const IgemmParams p) {
 
     const int lr = lane & 15;
     const int sw = lane & 7;  // (row & 7) of every fragment row this lane reads
-    const char* xs = smem + (wave_m * (BM / 2) + lr) * ROWB;
-    const char* ws = smem + XBYTES + (wave_n * (BN / 2) + lr) * ROWB;
+    const int xs_off = (wave_m * WROWS + lr) * ROWB;
+    const int ws_off = XBYTES + (wave_n * (BN / 2) + lr) * ROWB;
 
     int tap = t0, cstep = 0;
-    for (int kt = 0; kt < KT; ++kt) {
-        {
-            const int dy = p.tap_dy[tap];
-            const int dx = p.tap_dx[tap];
-            const int coff = cstep * BK + cc * 8;
-            const long wk = (long)p.tap_slot[tap] * p.Cin + coff;  // K offset in a weight row
-            const int xextra = coff >> p.cshift;
-            const int ch = coff & p.cmask;
+    // (dy, dx, weight slot) of the current tap, one dword from the kernel arguments (a scalar
+    // load); the next tap's dword is fetched a whole K step before it is needed
+    int info = p.tap_info[t0];
+    // issues the loads of the next K step into the tile at `dst` and advances (tap, cstep)
+    auto issue = [&](char* dst) {
+        const int dy = (int)(int8_t)(info & 0xff);
+        const int dx = (int)(int8_t)((info >> 8) & 0xff);
+        const int coff = cstep * BK + cc * 8;
+        const long wk = (long)(info >> 16) * p.Cin + coff;  // K offset in a weight row
+        const int xextra = coff >> p.cshift;
+        const int ch = coff & p.cmask;
 #pragma unroll
-            for (int i = 0; i < XI; ++i) {
-                const int iy = iy0[i] + dy;
-                const int ix = ix0[i] + dx + xextra;
-                const bool ok = (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
-                const long off = (long)(pixbase[i] + iy * p.Wi + ix) * p.Cx + ch;
-                const uint16_t* src = ok ? p.x + off : zero;
-                __builtin_amdgcn_global_load_lds((gptr_t)src,
-                                                 (lptr_t)(smem + (32 * i + 8 * wid) * ROWB), 16, 0, 0);
-            }
-#pragma unroll
-            for (int i = 0; i < WI; ++i) {
-                const int n = n0 + r0 + 32 * i;
-                const uint16_t* src = (n < p.N) ? wbase + ((long)n * ktot + wk) : zero;
-                __builtin_amdgcn_global_load_lds(
-                    (gptr_t)src, (lptr_t)(smem + XBYTES + (32 * i + 8 * wid) * ROWB), 16, 0, 0);
-            }
-            if (++cstep == kc) {
-                cstep = 0;
-                ++tap;
-            }
+        for (int i = 0; i < XI; ++i) {
+            const int iy = iy0[i] + dy;
+            const int ix = ix0[i] + dx + xextra;
+            const bool ok = (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+            const long off = (long)(pixbase[i] + iy * p.Wi + ix) * p.Cx + ch;
+            const uint16_t* src = ok ? p.x + off : zero;
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(dst + (RPI * i + 8 * wid) * ROWB),
+                                             16, 0, 0);
         }
-        __syncthreads();  // the compiler drains vmcnt before this barrier: the tile is in LDS
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            bf16x8 af[TN], bfr[TM];
-            const int slot0 = ((kk * 4 + (lane >> 4)) ^ sw) * 16;
+        for (int i = 0; i < WI; ++i) {
+            const int n = n0 + r0 + RPI * i;
+            const uint16_t* src = (n < p.N) ? wbase + ((long)n * ktot + wk) : zero;
+            __builtin_amdgcn_global_load_lds(
+                (gptr_t)src, (lptr_t)(dst + XBYTES + (RPI * i + 8 * wid) * ROWB), 16, 0, 0);
+        }
+        if (++cstep == kc) {
+            cstep = 0;
+            ++tap;
+            info = p.tap_info[tap & (kMaxTaps - 1)];
+        }
+    };
+    auto multiply = [&](const char* tile) {
+        const char* xs = tile + xs_off;
+        const char* ws = tile + ws_off;
+        if constexpr (PF) {
+            // every fragment of the K step is requested before the first MFMA, so LDS reads
+            // stream underneath the multiplies (costs 2 x (TN + TM) x 4 VGPRs)
+            bf16x8 af[2][TN], bfr[2][TM];
 #pragma unroll
-            for (int a = 0; a < TN; ++a)
-                af[a] = *reinterpret_cast<const bf16x8*>(ws + a * 16 * ROWB + slot0);
+            for (int kk = 0; kk < 2; ++kk) {
+                const int slot0 = ((kk * 4 + (lane >> 4)) ^ sw) * 16;
 #pragma unroll
-            for (int b = 0; b < TM; ++b)
-                bfr[b] = *reinterpret_cast<const bf16x8*>(xs + b * 16 * ROWB + slot0);
-#pragma unroll
-            for (int a = 0; a < TN; ++a)
+                for (int a = 0; a < TN; ++a)
+                    af[kk][a] = *reinterpret_cast<const bf16x8*>(ws + a * 16 * ROWB + slot0);
 #pragma unroll
                 for (int b = 0; b < TM; ++b)
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bfr[b], acc[a][b], 0, 0, 0);
+                    bfr[kk][b] = *reinterpret_cast<const bf16x8*>(xs + b * 16 * ROWB + slot0);
+            }
+            asm volatile("" ::: "memory");  // keeps the reads above the multiplies
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int a = 0; a < TN; ++a)
+#pragma unroll
+                    for (int b = 0; b < TM; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[kk][a], bfr[kk][b],
+                                                                            acc[a][b], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                bf16x8 af[TN], bfr[TM];
+                const int slot0 = ((kk * 4 + (lane >> 4)) ^ sw) * 16;
+#pragma unroll
+                for (int a = 0; a < TN; ++a)
+                    af[a] = *reinterpret_cast<const bf16x8*>(ws + a * 16 * ROWB + slot0);
+#pragma unroll
+                for (int b = 0; b < TM; ++b)
+                    bfr[b] = *reinterpret_cast<const bf16x8*>(xs + b * 16 * ROWB + slot0);
+#pragma unroll
+                for (int a = 0; a < TN; ++a)
+#pragma unroll
+                    for (int b = 0; b < TM; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bfr[b], acc[a][b], 0, 0, 0);
+            }
         }
-        __syncthreads();  // everyone has read the tile before the next K step overwrites it
+    };
+
+    if constexpr (DB) {
+        issue(smem);
+        __syncthreads();  // the compiler drains vmcnt before a barrier: tile 0 is in LDS
+        for (int kt = 0; kt < KT; ++kt) {
+            char* cur = smem + (kt & 1) * TILEB;
+            if (kt + 1 < KT) issue(smem + ((kt + 1) & 1) * TILEB);  // lands while we multiply
+            multiply(cur);
+            __syncthreads();  // next tile landed (vmcnt drained) and everyone is done with `cur`
+        }
+    } else {
+        for (int kt = 0; kt < KT; ++kt) {
+            issue(smem);
+            __syncthreads();  // the compiler drains vmcnt before this barrier: the tile is in LDS
+            multiply(smem);
+            __syncthreads();  // everyone has read the tile before the next K step overwrites it
+        }
     }
 
     // ---- epilogue
@@ -184,7 +257,7 @@ __global__ __launch_bounds__(256, 4) void igemm_kernel(const IgemmParams p) {
         constexpr int HALF = BN / 2;    // columns staged per pass (one wave_n half)
         constexpr int CP = HALF + 4;    // float pitch: 8-lane ds_write_b128 groups hit distinct banks
         constexpr int CPR = HALF / 8;   // 16-byte output chunks per pixel row
-        constexpr int RPP = 256 / CPR;  // pixel rows per pass of the store loop
+        constexpr int RPP = NT / CPR;   // pixel rows per pass of the store loop
         constexpr int NPASS = (BM + RPP - 1) / RPP;
         float* cs = reinterpret_cast<float*>(smem);
         const int chunk = tid % CPR;
@@ -203,7 +276,7 @@ __global__ __launch_bounds__(256, 4) void igemm_kernel(const IgemmParams p) {
                     }
 #pragma unroll
                     for (int b = 0; b < TM; ++b) {
-                        const int pr = wave_m * (BM / 2) + b * 16 + lr;
+                        const int pr = wave_m * WROWS + b * 16 + lr;
                         *reinterpret_cast<f32x4*>(cs + pr * CP + col) = acc[a][b] * sc + sh;
                     }
                 }
@@ -218,10 +291,9 @@ __global__ __launch_bounds__(256, 4) void igemm_kernel(const IgemmParams p) {
                     if (pr >= BM || m >= M) break;
                     long opix = m;
                     if (!identity) {
-                        const int bb = (int)(m / HoWo);
-                        const int rem = (int)(m - (long)bb * HoWo);
-                        const int oy = rem / Wo;
-                        const int ox = rem - oy * Wo;
+                        int bb, rem, oy, ox;
+                        fast_divmod((int)m, HoWo, inv_howo, bb, rem);
+                        fast_divmod(rem, Wo, inv_wo, oy, ox);
                         opix = (long)bb * OHW + (oy * p.osy + ooy) * p.OW + ox * p.osx + oox;
                     }
                     const f32x4 v0 = *reinterpret_cast<const f32x4*>(cs + pr * CP + chunk * 8);
@@ -256,7 +328,7 @@ __global__ __launch_bounds__(256, 4) void igemm_kernel(const IgemmParams p) {
     // general path: channel counts that are not multiples of 8, float32 NCHW output
 #pragma unroll
     for (int b = 0; b < TM; ++b) {
-        const long m = m0 + wave_m * (BM / 2) + b * 16 + lr;
+        const long m = m0 + wave_m * WROWS + b * 16 + lr;
         if (m >= M) continue;
         const int bb = (int)(m / HoWo);
         const int rem = (int)(m - (long)bb * HoWo);
@@ -283,11 +355,26 @@ __global__ __launch_bounds__(256, 4) void igemm_kernel(const IgemmParams p) {
     }
 }
 
-template <int BM, int BN>
+template <int BM, int BN, bool DB>
 static constexpr size_t lds_bytes() {
-    const size_t ktile = (size_t)(BM + BN) * ROWB;
+    const size_t ktile = (size_t)(BM + BN) * ROWB * (DB ? 2 : 1);
     const size_t etile = (size_t)BM * (BN / 2 + 4) * sizeof(float);
     return ktile > etile ? ktile : etile;
+}
+
+template <int BM, int BN, int WM, bool DB, bool PF, int MINB>
+static void launch_cfg(const IgemmParams& p, long maxM, hipStream_t st) {
+    const long ntm = (maxM + BM - 1) / BM;
+    const long ntn = (p.N + BN - 1) / BN;
+    const dim3 grid((unsigned)(ntm * ntn), (unsigned)p.nphase);
+    constexpr size_t lds = lds_bytes<BM, BN, DB>();
+    if constexpr (lds > 64 * 1024) {
+        static const hipError_t once = hipFuncSetAttribute(
+            reinterpret_cast<const void*>(&igemm_kernel<BM, BN, WM, DB, PF, MINB>),
+            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)once;
+    }
+    igemm_kernel<BM, BN, WM, DB, PF, MINB><<<grid, WM * 128, lds, st>>>(p);
 }
 
 int32_t igemm_launch(const IgemmParams& pin, hipStream_t st, const char* what) {
@@ -303,6 +390,10 @@ int32_t igemm_launch(const IgemmParams& pin, hipStream_t st, const char* what) {
         p.ph_Wo[0] = p.Wo;
         p.ph_woff[0] = 0;
     }
+    for (int i = 0; i < kMaxTaps; ++i)
+        p.tap_info[i] = (int32_t)((uint32_t)(uint8_t)(int8_t)p.tap_dy[i] |
+                                  ((uint32_t)(uint8_t)(int8_t)p.tap_dx[i] << 8) |
+                                  ((uint32_t)p.tap_slot[i] << 16));
     PE_REQUIRE(p.x && p.w && p.y, PE_E_INVALID, "%s: NULL tensor pointer", what);
     PE_REQUIRE(p.B > 0 && p.Hi > 0 && p.Wi > 0 && p.N > 0 && p.nphase <= kMaxPhases, PE_E_INVALID,
                "%s: sizes must be positive", what);
@@ -323,25 +414,44 @@ int32_t igemm_launch(const IgemmParams& pin, hipStream_t st, const char* what) {
         const long M = (long)p.B * p.ph_Ho[i] * p.ph_Wo[i];
         if (M > maxM) maxM = M;
     }
+    // the kernel's reciprocal-based index split needs quotients below 2^20
+    PE_REQUIRE(p.B < (1 << 20) && maxM / p.B < (1L << 22), PE_E_UNSUPPORTED,
+               "%s: batch or map size out of range", what);
+    for (int i = 0; i < kMaxTaps; ++i)
+        PE_REQUIRE(p.tap_dy[i] >= -128 && p.tap_dy[i] <= 127 && p.tap_dx[i] >= -128 &&
+                       p.tap_dx[i] <= 127,
+                   PE_E_UNSUPPORTED, "%s: tap offset out of range", what);
     PE_REQUIRE((long)p.B * p.Hi * p.Wi < 0x7fffffffL && maxM < 0x7fffffffL &&
                    (long)p.B * p.OH * p.OW < 0x7fffffffL,
                PE_E_UNSUPPORTED, "%s: pixel count does not fit int32", what);
 
     // tile choice: 128-pixel tiles unless they leave the chip under-filled
-    const int bn = p.N > 64 ? 128 : 64;
+    int bn = p.N > 64 ? 128 : 64;
     const long ntn = (p.N + bn - 1) / bn;
     const long wg128 = ((maxM + 127) / 128) * ntn * p.nphase;
-    const int bm = (wg128 < 768 && maxM > 64) ? 64 : 128;
-    const long ntm = (maxM + bm - 1) / bm;
-    const dim3 grid((unsigned)(ntm * ntn), (unsigned)p.nphase);
-    if (bm == 128 && bn == 128)
-        igemm_kernel<128, 128><<<grid, 256, lds_bytes<128, 128>(), st>>>(p);
-    else if (bm == 128)
-        igemm_kernel<128, 64><<<grid, 256, lds_bytes<128, 64>(), st>>>(p);
-    else if (bn == 128)
-        igemm_kernel<64, 128><<<grid, 256, lds_bytes<64, 128>(), st>>>(p);
-    else
-        igemm_kernel<64, 64><<<grid, 256, lds_bytes<64, 64>(), st>>>(p);
+    int bm = (wg128 < 768 && maxM > 64) ? 64 : 128;
+    int wm = 2, db = 0, pf = 0, minb = 4;
+    static const char* force = getenv("PE_IGEMM_CFG");  // "BM,BN,WM,DB,PF,MINB": tuning aid
+    if (force) sscanf(force, "%d,%d,%d,%d,%d,%d", &bm, &bn, &wm, &db, &pf, &minb);
+#define PE_CFG(BM_, BN_, WM_, DB_, PF_, MINB_)                                        \
+    if (bm == BM_ && bn == BN_ && wm == WM_ && db == (DB_ ? 1 : 0) && pf == (PF_ ? 1 : 0) && \
+        minb == MINB_) {                                                               \
+        launch_cfg<BM_, BN_, WM_, DB_, PF_, MINB_>(p, maxM, st);                       \
+        return check_launch(what);                                                     \
+    }
+    PE_CFG(128, 128, 2, false, false, 4)
+    PE_CFG(128, 64, 2, false, false, 4)
+    PE_CFG(64, 128, 2, false, false, 4)
+    PE_CFG(64, 64, 2, false, false, 4)
+    PE_CFG(128, 128, 2, false, true, 3)
+    PE_CFG(128, 128, 2, false, true, 4)
+    PE_CFG(128, 128, 2, true, true, 2)
+    PE_CFG(128, 128, 2, true, false, 2)
+    PE_CFG(256, 128, 4, false, true, 1)
+    PE_CFG(256, 128, 4, true, true, 1)
+    PE_CFG(128, 64, 2, false, true, 4)
+#undef PE_CFG
+    PE_REQUIRE(false, PE_E_UNSUPPORTED, "%s: no kernel for tile %dx%d wm %d db %d pf %d minb %d", what, bm, bn, wm, db, pf, minb);
     return check_launch(what);
 }
 
