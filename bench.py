@@ -158,6 +158,68 @@ class MseFused(Mse):
     fused = True
 
 
+VEC_PAIRS = [(5, 7), (7, 9), (6, 8), (8, 10), (11, 13), (13, 15), (12, 14), (14, 16), (5, 6),
+             (11, 12), (5, 11), (6, 12), (0, 5), (0, 6), (1, 2), (3, 4)]
+
+
+class VecRender(Workload):
+    """Vector-map labels: 256 images x 16 keypoint pairs = 64 channels of 64x48 per image."""
+    name = "vecmap_render_256x64x64x48_f32"
+    batch = 256
+    kernel = "vec_render_contig_kernel"
+    bytes_per_step = batch * 4 * len(VEC_PAIRS) * MAP_BYTES     # every map written in full
+
+    def setup(self, device):
+        from pose_estimation_amd import ops
+
+        self.ops = ops
+        self.j = torch.from_numpy(synthetic.joints(self.batch, K_JOINTS, 256, 192)).to(device)
+        self.outs = [torch.empty(self.batch, 4 * len(VEC_PAIRS), H, W, device=device)
+                     for _ in range(4)]
+
+    def step(self, i):
+        self.ops.render_vecmaps(self.j, VEC_PAIRS, H, W, 4.0, 2, out=self.outs[i % 4])
+
+    def cpu_baseline(self):
+        import oracle
+
+        j = synthetic.joints(16, K_JOINTS, 256, 192)
+        t0 = time.perf_counter()
+        oracle.render_vecmaps(j, VEC_PAIRS, H, W, 4.0, 2)
+        dt = time.perf_counter() - t0
+        return {"value": 16 / dt, "unit": "images/s", "cores": 1, "kind": "port",
+                "sample": "NumPy oracle, 16-image batch, one run"}
+
+
+class VecLoss(VecRender):
+    """Vector-map loss + gradient: the label is rebuilt in registers; pred is read only near
+    the windows, the gradient is written in full."""
+    name = "vecmap_loss_256x64x64x48_f32"
+    kernel = "vec_loss_kernel"
+    bytes_per_step = 256 * 4 * len(VEC_PAIRS) * MAP_BYTES       # the gradient write
+
+    def setup(self, device):
+        super().setup(device)
+        g = torch.Generator(device=device).manual_seed(7)
+        self.preds = [torch.randn(self.batch, 4 * len(VEC_PAIRS), H, W, device=device, generator=g)
+                      for _ in range(3)]
+        self.ws = torch.empty(1 << 20, dtype=torch.uint8, device=device)
+
+    def step(self, i):
+        self.ops.vecmap_loss_fwd_bwd(self.preds[i % 3], self.j, VEC_PAIRS, 4.0, 2, workspace=self.ws)
+
+    def cpu_baseline(self):
+        import oracle
+
+        j = synthetic.joints(16, K_JOINTS, 256, 192)
+        p = np.random.default_rng(0).normal(size=(16, 4 * len(VEC_PAIRS), H, W)).astype(np.float32)
+        t0 = time.perf_counter()
+        oracle.vecmap_loss_fwd_bwd(p, j, VEC_PAIRS, 4.0, 2)
+        dt = time.perf_counter() - t0
+        return {"value": 16 / dt, "unit": "images/s", "cores": 1, "kind": "port",
+                "sample": "NumPy oracle, 16-image batch, one run"}
+
+
 class Adam(Workload):
     name = "adam_34M_f32"
     batch = 1  # one optimizer step
@@ -300,6 +362,7 @@ class Train(Workload):
 
 
 WORKLOADS = {"decode": Decode, "render": Render, "mse": Mse, "mse_fused": MseFused, "adam": Adam,
+             "vecmap": VecRender, "vecmap_loss": VecLoss,
              "infer": Infer, "train": Train}
 
 

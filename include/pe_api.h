@@ -80,8 +80,9 @@ int32_t pe_decode_f32(const float* hm, int32_t B, int32_t K, int32_t H, int32_t 
  *
  * pe_render_targets_f32: joints [B,K,3] float32 = (x, y, v) in input pixels.
  *   mu      = floor(coord / stride + 0.5)       (float32 arithmetic)
- *   weight  = 0 if !(v > 0), if a coordinate is not finite, or if the
- *             (2*radius+1)^2 window around mu lies wholly off the map; else 1
+ *   weight  = 0 if !(v > 0), if a coordinate is not finite, or if the centre
+ *             cell mu is off the map (the label of test.ipynb:606-653 leaves
+ *             the heat map of such a joint empty); else 1
  *   target  = table[|x-mu_x|] * table[|y-mu_y|] inside the window, 0 elsewhere,
  *             all 0 when weight == 0
  * target is a logical [B,K,H,W] float32 tensor addressed through
@@ -93,6 +94,43 @@ int32_t pe_render_targets_f32(const float* joints, int32_t B, int32_t K, int32_t
                               float stride, float sigma, int32_t radius,
                               float* target, int64_t tB, int64_t tK, int64_t tH, int64_t tW,
                               float* weight, pe_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * Vector-map labels and their loss (the reference's second dense label).
+ * Replaces: the `vecmaps` label rendering of dataset/pose_data.py
+ * (PoseEstimation.pyproj:27; absent), whose output is printed at
+ * test.ipynb:634-653 and read back by the drawing cell as vecmaps[y, x, 4*i]
+ * (x offset) and vecmaps[y, x, 4*i + 1] (y offset), in cells.
+ *
+ * pairs_host: HOST array of 2*num_pairs joint indices (num_pairs <= 32).
+ * vec is a logical [B, 4*num_pairs, H, W] float32 tensor addressed through
+ * element strides (sB,sC,sH,sW); NHWC is (H*W*C, 1, W*C, C).  For pair
+ * i = (k1, k2) with centres c = floor(coord/stride + 0.5):
+ *   channel 4i, 4i+1   : cells with |x-c1.x| <= radius and |y-c1.y| <= radius
+ *                        hold (c2.x - x, c2.y - y)
+ *   channel 4i+2, 4i+3 : cells of k2's window hold (c1.x - x, c1.y - y)
+ * everything else is 0.  Windows are clipped to the map and a centre may lie
+ * off the map; both joints must be labelled (v > 0) and finite.
+ *
+ * pe_vecmap_loss_fwd_bwd: pred / grad contiguous [B, 4*num_pairs, H, W],
+ * float32 or bf16;  L = 0.5/n * sum over window cells of m * (p - t)^2,
+ * grad = m * (p - t) / n inside windows and 0 elsewhere, n = B*4*num_pairs*H*W.
+ * The label is rebuilt in registers, never read from memory.  mask [B,H,W]
+ * uint8 (NULL = none); per_channel: 4*num_pairs floats, mean == loss (may be
+ * NULL); grad may be NULL; workspace >= pe_vecmap_workspace_bytes(B, num_pairs).
+ * ---------------------------------------------------------------------- */
+int32_t pe_render_vecmaps_f32(const float* joints, int32_t B, int32_t K,
+                              const int32_t* pairs_host, int32_t num_pairs, int32_t H, int32_t W,
+                              float stride, int32_t radius, float* vec, int64_t sB, int64_t sC,
+                              int64_t sH, int64_t sW, pe_stream_t stream);
+
+size_t pe_vecmap_workspace_bytes(int32_t B, int32_t num_pairs);
+
+int32_t pe_vecmap_loss_fwd_bwd(const void* pred, int32_t pred_dtype, const float* joints,
+                               const uint8_t* mask, int32_t B, int32_t K,
+                               const int32_t* pairs_host, int32_t num_pairs, int32_t H, int32_t W,
+                               float stride, int32_t radius, float* loss, float* per_channel,
+                               void* grad, void* workspace, pe_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * a3. Masked per-joint MSE loss and its gradient.

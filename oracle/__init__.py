@@ -10,6 +10,8 @@ PoseEstimation.pyproj:22-40 is absent), so these functions restate the
 top-down "simple baselines" formulation rather than reference source.  The
 only reference-held facts they are pinned against are notebook outputs:
   * heat-map support of test.ipynb:606-614 (five 3x3 blocks on a 40x40x3 map),
+  * vector-map support of test.ipynb:634-653 (116 non-zero cells of the 40x40x8 map
+    of the same label, including a keypoint whose centre is off the map),
   * stride 8 / 320x320 -> 40x40 (test.ipynb:919, 928, 1010),
   * Adam hyper-parameters (test.ipynb:1001-1008).
 """
@@ -17,6 +19,8 @@ from .numpy_oracle import (  # noqa: F401
     decode_heatmaps,
     gaussian_table,
     render_targets,
+    render_vecmaps,
+    vecmap_loss_fwd_bwd,
     mse_fwd_bwd,
     adam_step,
     sgd_step,

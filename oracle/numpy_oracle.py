@@ -114,7 +114,10 @@ def render_targets(joints, H: int, W: int, stride: float, sigma: float, radius: 
     target [B, K, H, W] float32 and weight [B, K] float32.
 
     weight = 0 when v == 0 (or v is not > 0), when a coordinate is not finite,
-    or when the (2r+1)^2 window around mu lies wholly off the map; else 1.
+    or when the centre cell mu lies off the map; else 1.  (The reference's label
+    of test.ipynb:606-653 has a keypoint whose centre is one column past the
+    right edge: its vector-map entries exist in the clipped window but its heat
+    map is empty, so a joint is drawn only when its centre cell is on the map.)
     target = g[|x - mu_x|] * g[|y - mu_y|] (one float32 product) inside the
     window, 0 elsewhere, and all zeros when weight == 0.
     With radius = 1 the support is the 3x3 block the reference's label maps
@@ -128,7 +131,7 @@ def render_targets(joints, H: int, W: int, stride: float, sigma: float, radius: 
     mx, my = joint_centres(j, stride)
     finite = np.isfinite(j[..., 0]) & np.isfinite(j[..., 1])
     with np.errstate(invalid="ignore"):
-        on = (mx - r < W) & (mx + r >= 0) & (my - r < H) & (my + r >= 0)
+        on = (mx < W) & (mx >= 0) & (my < H) & (my >= 0)
         vis = j[..., 2] > 0
     wgt = (finite & on & vis)
     target = np.zeros((B, K, H, W), dtype=F32)
@@ -146,6 +149,90 @@ def render_targets(joints, H: int, W: int, stride: float, sigma: float, radius: 
             gy = np.where(ay <= r, g[np.minimum(ay, r)], F32(0)).astype(F32)
             target[b, k] = gy[:, None] * gx[None, :]
     return target, wgt.astype(F32)
+
+
+# --------------------------------------------------------------------------
+# vector maps: per keypoint pair, the integer cell offset to the partner joint
+# --------------------------------------------------------------------------
+VEC_MAX_CENTRE = 1 << 20  # centres further out than this are treated as unlabelled
+
+
+def render_vecmaps(joints, pairs, H: int, W: int, stride: float, radius: int):
+    """Vector-map labels.  joints [B, K, 3] float32 (x, y, v); pairs = [(k1, k2), ...].
+
+    Returns vec [B, 4*P, H, W] float32 and support (bool, same shape).  For pair
+    i = (k1, k2) with centres c1, c2 (joint_centres):
+      channel 4i   at cells of k1's window: c2.x - x     channel 4i+1: c2.y - y
+      channel 4i+2 at cells of k2's window: c1.x - x     channel 4i+3: c1.y - y
+    The window is the (2r+1)^2 block around the joint's centre clipped to the
+    map; a centre may lie off the map (the entries in the clipped window stay,
+    and offsets still point at the off-map centre).  Both joints must be
+    labelled (v > 0) and finite, else all four channels are empty.
+    Follows the reference's label printed at test.ipynb:634-653 (8 channels for
+    pairs [[0, 1], [2, 1]], 3x3 windows, channel use read off the zero pattern:
+    an offset component that is 0 is missing from the non-zero list) and the
+    channel indexing of its drawing cell (test.ipynb: vecmaps[y, x, 4*i],
+    vecmaps[y, x, 4*i + 1] scaled by the stride give the line to the partner).
+    """
+    j = np.asarray(joints, dtype=F32)
+    B, K, _ = j.shape
+    r = int(radius)
+    P = len(pairs)
+    mx, my = joint_centres(j, stride)
+    with np.errstate(invalid="ignore"):
+        ok = (np.isfinite(j[..., 0]) & np.isfinite(j[..., 1]) & (j[..., 2] > 0)
+              & (np.abs(mx) < VEC_MAX_CENTRE) & (np.abs(my) < VEC_MAX_CENTRE))
+    vec = np.zeros((B, 4 * P, H, W), dtype=F32)
+    sup = np.zeros((B, 4 * P, H, W), dtype=bool)
+    xs = np.arange(W, dtype=np.int64)
+    ys = np.arange(H, dtype=np.int64)
+    for b in range(B):
+        for i, (k1, k2) in enumerate(pairs):
+            if not (ok[b, k1] and ok[b, k2]):
+                continue
+            for half, (ks, kd) in enumerate(((k1, k2), (k2, k1))):
+                sx, sy = int(mx[b, ks]), int(my[b, ks])
+                dx, dy = int(mx[b, kd]), int(my[b, kd])
+                win = (np.abs(ys - sy) <= r)[:, None] & (np.abs(xs - sx) <= r)[None, :]
+                c = 4 * i + 2 * half
+                vec[b, c] = np.where(win, (dx - xs)[None, :], 0).astype(F32)
+                vec[b, c + 1] = np.where(win, (dy - ys)[:, None], 0).astype(F32)
+                sup[b, c] = win
+                sup[b, c + 1] = win
+    return vec, sup
+
+
+def vecmap_loss_fwd_bwd(pred, joints, pairs, stride: float, radius: int, mask=None,
+                        pred_is_bf16: bool = False):
+    """L = 0.5/n * sum over supported cells of m (p - t)^2 and dL/dp, n = B*4P*H*W.
+
+    pred [B, 4P, H, W] float32 (or bf16 bits); t and the support come from
+    render_vecmaps; cells outside the support carry no loss and no gradient
+    (the offset is undefined there).  Returns loss, per_channel [4P] (mean of
+    per_channel == loss) and grad.  Float32 order: d = p - t; q = d*d;
+    grad = inv_n * d with inv_n = float32(1/n).
+    """
+    if pred_is_bf16:
+        p = bf16_bits_to_f32(pred)
+    else:
+        p = np.asarray(pred, dtype=F32)
+    B, C, H, W = p.shape
+    t, sup = render_vecmaps(joints, pairs, H, W, stride, radius)
+    n = B * C * H * W
+    inv_n = F32(1.0 / n)
+    d = (p - t).astype(F32)
+    q = (d * d).astype(F32)
+    g = (inv_n * d).astype(F32)
+    keep = sup
+    if mask is not None:
+        keep = keep & np.asarray(mask).astype(bool)[:, None, :, :]
+    q = np.where(keep, q, F32(0))
+    g = np.where(keep, g, F32(0)).astype(F32)
+    sums = q.astype(np.float64).sum(axis=(0, 2, 3))
+    per_channel = (sums * (0.5 / (B * H * W))).astype(F32)
+    loss = F32(sums.sum() * (0.5 / n))
+    grad = f32_to_bf16_bits(g) if pred_is_bf16 else g
+    return loss, per_channel, grad
 
 
 # --------------------------------------------------------------------------

@@ -14,6 +14,8 @@ from .ops import (  # noqa: F401
     mse_fwd_bwd,
     mse_workspace,
     render_targets,
+    render_vecmaps,
+    vecmap_loss_fwd_bwd,
     sgd_step,
 )
 

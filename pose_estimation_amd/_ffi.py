@@ -45,6 +45,17 @@ SIGNATURES = {
         [c_void_p, c_int32, c_int32, c_int32, c_int32, c_float, c_float, c_int32,
          c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p, c_void_p],
     ),
+    "pe_render_vecmaps_f32": (
+        c_int32,
+        [c_void_p, c_int32, c_int32, c_void_p, c_int32, c_int32, c_int32, c_float, c_int32,
+         c_void_p, c_int64, c_int64, c_int64, c_int64, c_void_p],
+    ),
+    "pe_vecmap_workspace_bytes": (c_size_t, [c_int32, c_int32]),
+    "pe_vecmap_loss_fwd_bwd": (
+        c_int32,
+        [c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_int32, c_void_p, c_int32, c_int32,
+         c_int32, c_float, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
+    ),
     "pe_mse_workspace_bytes": (c_size_t, [c_int32, c_int32]),
     "pe_mse_fwd_bwd": (
         c_int32,

@@ -22,6 +22,12 @@ struct GaussTable {
 // Fills t.g[0..radius] exactly as pe_gaussian_table_f32 does; entries past radius are 0.
 void fill_gauss_table(float sigma, int radius, GaussTable* t);
 
+// Stage 2 of the two-stage loss reductions (pe_mse.hip): partial[b*K + k] -> per_map[k] =
+// per_map_scale * sum_b, loss = loss_scale * sum_k sum_b, in a fixed order (K <= 4096).
+int32_t launch_map_sum_reduce(const float* partial, int B, int K, float per_map_scale,
+                              float loss_scale, float* per_map, float* loss, hipStream_t st,
+                              const char* what);
+
 inline hipStream_t as_stream(pe_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
 // Checks the launch that was just enqueued; returns PE_OK or PE_E_HIP.

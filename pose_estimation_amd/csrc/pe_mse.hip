@@ -174,6 +174,14 @@ __global__ __launch_bounds__(256) void mse_reduce_kernel(const float* __restrict
     }
 }
 
+int32_t launch_map_sum_reduce(const float* partial, int B, int K, float per_map_scale,
+                              float loss_scale, float* per_map, float* loss, hipStream_t st,
+                              const char* what) {
+    mse_reduce_kernel<<<1, 256, (size_t)K * sizeof(float), st>>>(partial, B, K, per_map_scale,
+                                                                loss_scale, per_map, loss);
+    return check_launch(what);
+}
+
 template <bool BF16, bool FUSED>
 static void launch_mse(const MseArgs& a, const GaussTable& tab, unsigned grid, hipStream_t st) {
     const bool hm = a.mask != nullptr, hg = a.grad != nullptr;
@@ -259,7 +267,6 @@ extern "C" int32_t pe_mse_fwd_bwd(const void* pred, int32_t pred_dtype, const fl
     if (rc != PE_OK) return rc;
     const float joint_scale = (float)(0.5 / ((double)B * H * W));
     const float loss_scale = (float)(0.5 / n);
-    mse_reduce_kernel<<<1, 256, (size_t)K * sizeof(float), st>>>(a.partial, B, K, joint_scale,
-                                                                loss_scale, per_joint, loss);
-    return check_launch("pe_mse_fwd_bwd(stage 2)");
+    return launch_map_sum_reduce(a.partial, B, K, joint_scale, loss_scale, per_joint, loss, st,
+                                 "pe_mse_fwd_bwd(stage 2)");
 }

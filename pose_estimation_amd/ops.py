@@ -123,6 +123,96 @@ def render_targets(joints: torch.Tensor, H: int, W: int, stride: float, sigma: f
 
 
 # ---------------------------------------------------------------------------
+# vector maps (keypoint-pair offset fields): labels and loss
+# ---------------------------------------------------------------------------
+def _pairs_array(pairs) -> np.ndarray:
+    arr = np.ascontiguousarray(np.asarray(pairs, dtype=np.int32).reshape(-1, 2))
+    if arr.shape[0] == 0:
+        raise ValueError("pairs must hold at least one (k1, k2)")
+    return arr
+
+
+def render_vecmaps(joints: torch.Tensor, pairs, H: int, W: int, stride: float, radius: int = 1,
+                   layout: str = "NCHW", out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Vector-map labels from joints [B,K,3]: [B,4P,H,W] ("NCHW") or [B,H,W,4P] ("NHWC", the
+    reference's layout).  Channel 4i, 4i+1 = (x, y) cell offset to the second joint of pair i
+    inside the first joint's window; 4i+2, 4i+3 the reverse."""
+    _need_gpu(joints, out)
+    if joints.dtype != torch.float32 or joints.dim() != 3 or joints.shape[2] != 3:
+        raise ValueError("joints must be float32 [B,K,3]")
+    joints = joints.contiguous()
+    B, K, _ = joints.shape
+    pa = _pairs_array(pairs)
+    C = 4 * pa.shape[0]
+    if layout == "NCHW":
+        shape = (B, C, H, W)
+    elif layout == "NHWC":
+        shape = (B, H, W, C)
+    else:
+        raise ValueError(f"unknown layout {layout!r}")
+    if out is None:
+        out = torch.empty(shape, dtype=torch.float32, device=joints.device)
+    elif tuple(out.shape) != shape or out.dtype != torch.float32:
+        raise ValueError(f"out must be float32 {shape}")
+    if layout == "NCHW":
+        sB, sC, sH, sW = out.stride()
+    else:
+        sB, sH, sW, sC = out.stride()
+    with torch.cuda.device(joints.device):
+        check(lib().pe_render_vecmaps_f32(joints.data_ptr(), B, K, pa.ctypes.data, pa.shape[0], H, W,
+                                          float(stride), int(radius), out.data_ptr(), sB, sC, sH,
+                                          sW, _stream(joints)))
+    return out
+
+
+def vecmap_loss_fwd_bwd(pred: torch.Tensor, joints: torch.Tensor, pairs, stride: float,
+                        radius: int = 1, mask: Optional[torch.Tensor] = None,
+                        need_grad: bool = True, workspace: Optional[torch.Tensor] = None):
+    """Squared-error loss of a predicted vector map against the label rebuilt from the joints,
+    over window cells only.  pred [B,4P,H,W] float32 or bfloat16 contiguous.
+    Returns (loss [1], per_channel [4P], grad or None)."""
+    _need_gpu(pred, joints, mask, workspace)
+    if pred.dim() != 4 or not pred.is_contiguous():
+        raise ValueError("pred must be a contiguous [B,4P,H,W] tensor")
+    if pred.dtype == torch.float32:
+        dt = PE_DTYPE_F32
+    elif pred.dtype == torch.bfloat16:
+        dt = PE_DTYPE_BF16
+    else:
+        raise ValueError("pred must be float32 or bfloat16")
+    B, C, H, W = pred.shape
+    pa = _pairs_array(pairs)
+    if C != 4 * pa.shape[0]:
+        raise ValueError(f"pred has {C} channels, expected {4 * pa.shape[0]}")
+    if joints.dtype != torch.float32 or joints.dim() != 3 or joints.shape[0] != B or \
+            joints.shape[2] != 3:
+        raise ValueError("joints must be float32 [B,K,3]")
+    joints = joints.contiguous()
+    if mask is not None:
+        if tuple(mask.shape) != (B, H, W):
+            raise ValueError(f"mask must be [B,H,W] = {(B, H, W)}, got {tuple(mask.shape)}")
+        if mask.dtype == torch.bool:
+            mask = mask.view(torch.uint8)
+        if mask.dtype != torch.uint8:
+            raise ValueError("mask must be uint8 or bool")
+        mask = mask.contiguous()
+    dev = pred.device
+    if workspace is None:
+        workspace = torch.empty(lib().pe_vecmap_workspace_bytes(B, pa.shape[0]), dtype=torch.uint8,
+                                device=dev)
+    loss = torch.empty(1, dtype=torch.float32, device=dev)
+    per_channel = torch.empty(C, dtype=torch.float32, device=dev)
+    grad = torch.empty_like(pred) if need_grad else None
+    with torch.cuda.device(dev):
+        check(lib().pe_vecmap_loss_fwd_bwd(pred.data_ptr(), dt, joints.data_ptr(), _ptr(mask), B,
+                                           joints.shape[1], pa.ctypes.data, pa.shape[0], H, W,
+                                           float(stride), int(radius), loss.data_ptr(),
+                                           per_channel.data_ptr(), _ptr(grad),
+                                           workspace.data_ptr(), _stream(pred)))
+    return loss, per_channel, grad
+
+
+# ---------------------------------------------------------------------------
 # a3 masked MSE loss + gradient
 # ---------------------------------------------------------------------------
 def mse_workspace(B: int, K: int, device) -> torch.Tensor:

@@ -27,6 +27,7 @@ BLOCK_SHAPE = (2, 8, 6, 256)     # NHWC input of layer1's second bottleneck (ide
 DECONV_SHAPE = (1, 4, 3, 256)    # NHWC input of the second deconv (256 -> 256)
 WEIGHT_SEED = 31
 SAMPLE_STEP = 97                 # weight gradients are stored at every 97th packed element
+VEC_PAIRS = [(0, 1), (2, 1), (5, 7), (11, 13), (0, 2)]   # (0, 2) pairs two off-map centres
 
 
 def adversarial_maps(H=64, W=48):
@@ -73,10 +74,18 @@ def main():
     v.update(decode_hm=hm, decode_xy=xy, decode_conf=conf, decode_idx=idx.astype(np.int32))
     # ---- a2 render
     joints = synthetic.joints(4, 17, 256, 192, seed=2)
-    joints[0, 0, :2] = (-30.0, 10.0)      # window fully off the map: weight 0
-    joints[0, 1, :2] = (1.0, 255.0)       # clipped at two borders
+    joints[0, 0] = (-30.0, 10.0, 2)       # centre far off the map: weight 0
+    joints[0, 1] = (1.0, 253.0, 2)        # centre in the corner: window clipped at two borders
+    joints[0, 2] = (192.0, 100.0, 2)      # centre one cell past the right edge: weight 0
     t, w = oracle.render_targets(joints, 64, 48, 4.0, 2.0, 6)
     v.update(render_joints=joints, render_target=t, render_weight=w)
+    # ---- vector maps: labels for the first two images, loss + grad on noisy predictions
+    vec, sup = oracle.render_vecmaps(joints[:2], VEC_PAIRS, 64, 48, 4.0, 2)
+    vpred = (vec + np.random.Generator(np.random.PCG64(6)).normal(0, 0.5, vec.shape)).astype(np.float32)
+    vl, vpc, vg = oracle.vecmap_loss_fwd_bwd(vpred, joints[:2], VEC_PAIRS, 4.0, 2,
+                                             synthetic.ignore_mask(2, 64, 48, seed=4))
+    v.update(vec_label=vec, vec_pred=vpred, vec_loss=np.float32(vl), vec_per_channel=vpc,
+             vec_grad=vg)
     # ---- a3 loss + grad
     rng = np.random.Generator(np.random.PCG64(5))
     pred = (t[:2] + rng.normal(0, 0.1, t[:2].shape)).astype(np.float32)

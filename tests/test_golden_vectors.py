@@ -54,6 +54,14 @@ def test_oracle_render_loss_optim_match_golden(v):
     t, w = oracle.render_targets(v["render_joints"], 64, 48, 4.0, 2.0, 6)
     assert np.array_equal(t, v["render_target"]) and np.array_equal(w, v["render_weight"])
     assert w[0, 0] == 0.0 and not t[0, 0].any()
+    assert w[0, 2] == 0.0 and w[0, 1] == 1.0 and t[0, 1, 63, 0] == 1.0
+    vec, sup = oracle.render_vecmaps(v["render_joints"][:2], mk.VEC_PAIRS, 64, 48, 4.0, 2)
+    assert np.array_equal(vec, v["vec_label"])
+    assert vec[0, 16:20].any()   # both centres of pair (0, 2) are off the map, windows are not
+    vl, vpc, vg = oracle.vecmap_loss_fwd_bwd(v["vec_pred"], v["render_joints"][:2], mk.VEC_PAIRS,
+                                             4.0, 2, v["mse_mask"])
+    assert np.float32(vl) == v["vec_loss"] and np.array_equal(vpc, v["vec_per_channel"])
+    assert np.array_equal(vg, v["vec_grad"])
     loss, pj, grad = oracle.mse_fwd_bwd(v["mse_pred"], t[:2], w[:2], v["mse_mask"])
     assert np.float32(loss) == v["mse_loss"]
     assert np.array_equal(pj, v["mse_per_joint"]) and np.array_equal(grad, v["mse_grad"])
@@ -102,6 +110,16 @@ def test_hip_units_match_golden(v):
         assert loss.item() == pytest.approx(float(v["mse_loss"]), rel=2e-6)
         assert np.allclose(pj.cpu().numpy(), v["mse_per_joint"], rtol=2e-6, atol=0)
         assert np.array_equal(grad.cpu().numpy(), v["mse_grad"])
+    jv = cu(v["render_joints"][:2])
+    assert np.array_equal(ops.render_vecmaps(jv, mk.VEC_PAIRS, 64, 48, 4.0, 2).cpu().numpy(),
+                          v["vec_label"])
+    nhwc = ops.render_vecmaps(jv, mk.VEC_PAIRS, 64, 48, 4.0, 2, layout="NHWC")
+    assert np.array_equal(nhwc.permute(0, 3, 1, 2).cpu().numpy(), v["vec_label"])
+    vl, vpc, vg = ops.vecmap_loss_fwd_bwd(cu(v["vec_pred"]), jv, mk.VEC_PAIRS, 4.0, 2,
+                                          mask=cu(v["mse_mask"]))
+    assert vl.item() == pytest.approx(float(v["vec_loss"]), rel=2e-6)
+    assert np.allclose(vpc.cpu().numpy(), v["vec_per_channel"], rtol=2e-6, atol=0)
+    assert np.array_equal(vg.cpu().numpy(), v["vec_grad"])
     p, m, s = cu(v["adam_p0"]), torch.zeros(1000).cuda(), torch.zeros(1000).cuda()
     pb = torch.empty(1000, dtype=torch.bfloat16).cuda()
     for step in range(3):

@@ -7,7 +7,7 @@ import torch
 
 import oracle
 import pose_estimation_amd as pe
-from pose_estimation_amd import synthetic
+from pose_estimation_amd import ops, synthetic
 
 pytestmark = pytest.mark.gpu
 F32 = np.float32
@@ -182,6 +182,95 @@ def test_render_then_decode_round_trip_full_size():
     assert np.all(conf.cpu().numpy()[inside] == 1.0)
     assert np.all(conf.cpu().numpy()[~on] == 0.0)
     assert float(t.max()) == 1.0 and float(t.min()) == 0.0
+
+
+# ------------------------------------------------------------------ vector maps
+COCO_PAIRS = [(5, 7), (7, 9), (6, 8), (8, 10), (11, 13), (13, 15), (12, 14), (14, 16), (5, 6),
+              (11, 12), (5, 11), (6, 12), (0, 5), (0, 6), (1, 2), (3, 4)]
+
+
+def _vec_joints(B, K, H, W, stride, seed=2):
+    j = synthetic.joints(B, K, int(H * stride), int(W * stride), seed=seed)
+    j[0, 5] = (W * stride + 1.0, 20.0, 2)         # centre one cell past the right edge
+    j[0, 7] = (-3 * stride, -3 * stride, 1)       # window wholly off the map
+    j[0, 6] = (float("nan"), 3.0, 1)
+    j[-1, 11] = (1e30, 5.0, 1)                    # beyond the representable centre range
+    return j
+
+
+@pytest.mark.parametrize("cfg", [(4, 17, 64, 48, 4.0, 2), (2, 17, 96, 72, 4.0, 3),
+                                 (3, 17, 40, 40, 8.0, 1), (2, 17, 10, 7, 4.0, 4)])
+def test_vecmap_render_matches_oracle_bit_for_bit(cfg):
+    B, K, H, W, stride, r = cfg
+    j = _vec_joints(B, K, H, W, stride)
+    want, _ = oracle.render_vecmaps(j, COCO_PAIRS, H, W, stride, r)
+    got = ops.render_vecmaps(dev(j), COCO_PAIRS, H, W, stride, r)
+    assert np.array_equal(got.cpu().numpy(), want)
+    nhwc = ops.render_vecmaps(dev(j), COCO_PAIRS, H, W, stride, r, layout="NHWC")
+    assert np.array_equal(nhwc.permute(0, 3, 1, 2).cpu().numpy(), want)
+
+
+@pytest.mark.parametrize("use_mask", [False, True])
+@pytest.mark.parametrize("bf16", [False, True])
+def test_vecmap_loss_matches_oracle(use_mask, bf16):
+    B, K, H, W, stride, r = 3, 17, 64, 48, 4.0, 2
+    j = _vec_joints(B, K, H, W, stride)
+    rng = np.random.default_rng(5)
+    t, _ = oracle.render_vecmaps(j, COCO_PAIRS, H, W, stride, r)
+    p = (t + rng.normal(0, 1.0, t.shape)).astype(F32)
+    m = synthetic.ignore_mask(B, H, W, seed=4) if use_mask else None
+    if bf16:
+        pb = oracle.f32_to_bf16_bits(p)
+        want_l, want_pc, want_g = oracle.vecmap_loss_fwd_bwd(pb, j, COCO_PAIRS, stride, r, m,
+                                                             pred_is_bf16=True)
+        pt = torch.from_numpy(pb.view(np.int16)).cuda().view(torch.bfloat16)
+    else:
+        want_l, want_pc, want_g = oracle.vecmap_loss_fwd_bwd(p, j, COCO_PAIRS, stride, r, m)
+        pt = dev(p)
+    loss, pc, g = ops.vecmap_loss_fwd_bwd(pt, dev(j), COCO_PAIRS, stride, r,
+                                          mask=dev(m) if use_mask else None)
+    assert loss.item() == pytest.approx(float(want_l), rel=2e-6)   # float32 tree vs float64 sum
+    assert np.allclose(pc.cpu().numpy(), want_pc, rtol=2e-6, atol=1e-12)
+    if bf16:
+        assert np.array_equal(g.view(torch.int16).cpu().numpy().view(np.uint16), want_g)
+    else:
+        assert np.array_equal(g.cpu().numpy(), want_g)
+    l2, _, none = ops.vecmap_loss_fwd_bwd(pt, dev(j), COCO_PAIRS, stride, r,
+                                          mask=dev(m) if use_mask else None, need_grad=False)
+    assert none is None and torch.equal(l2, loss)      # fixed reduction order: bit-stable
+
+
+def test_vecmap_full_size_properties():
+    """Batch 64 x 17 joints, 16 pairs: cell + offset lands on the partner's centre everywhere,
+    and a prediction equal to the label has zero loss and zero gradient."""
+    B, K, H, W, stride, r = 64, 17, 64, 48, 4.0, 2
+    j = synthetic.joints(B, K, 256, 192, seed=2)
+    vec = ops.render_vecmaps(dev(j), COCO_PAIRS, H, W, stride, r)
+    mx, my = oracle.numpy_oracle.joint_centres(j, stride)
+    v = vec.cpu().numpy()
+    xs = np.arange(W)[None, :]
+    ys = np.arange(H)[:, None]
+    for i, (k1, k2) in enumerate(COCO_PAIRS[:4]):
+        for b in range(0, B, 7):
+            if not (j[b, k1, 2] > 0 and j[b, k2, 2] > 0):
+                assert not v[b, 4 * i:4 * i + 4].any()
+                continue
+            win = (np.abs(xs - mx[b, k1]) <= r) & (np.abs(ys - my[b, k1]) <= r)
+            assert np.all((v[b, 4 * i] + xs)[win] == mx[b, k2])
+            assert np.all((v[b, 4 * i + 1] + ys)[win] == my[b, k2])
+            assert not v[b, 4 * i][~win].any()
+    loss, pc, g = ops.vecmap_loss_fwd_bwd(vec, dev(j), COCO_PAIRS, stride, r)
+    assert loss.item() == 0.0 and not g.any()
+
+
+def test_vecmap_argument_errors():
+    j = dev(synthetic.joints(1, 17, 256, 192, seed=2))
+    with pytest.raises(pe._ffi.PeError):
+        ops.render_vecmaps(j, [(0, 17)], 64, 48, 4.0, 1)          # joint index out of range
+    with pytest.raises(pe._ffi.PeError):
+        ops.render_vecmaps(j, [(0, 1)] * 33, 64, 48, 4.0, 1)      # more than 32 pairs
+    with pytest.raises(RuntimeError):
+        ops.vecmap_loss_fwd_bwd(torch.zeros(1, 4, 64, 48), j, [(0, 1)], 4.0, 1)   # CPU tensor
 
 
 # ------------------------------------------------------------------ loss

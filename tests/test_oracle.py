@@ -132,27 +132,89 @@ def test_render_edge_cases():
         [21.9, 25.9, 1],            # 1 sub-pixel: 5.475+.5 -> 5, 6.475+.5 -> 6
         [22.0, 26.0, 1],            # 2 exactly .5 -> rounds up: (6, 7)
         [0.0, 0.0, 1],              # 3 window clipped at the top-left corner
-        [47.9, 63.9, 1],            # 4 clipped at the bottom-right: centre (12, 16) off-map by one
-        [-12.1, 10.0, 1],           # 5 centre -3: window [-6, 0] still touches column 0
-        [-16.1, 10.0, 1],           # 6 centre -4: window [-7,-1] fully off -> weight 0
-        [60.0, 10.0, 1],            # 7 centre 15: window [12,18] fully off (W = 12) -> weight 0
+        [45.9, 61.9, 1],            # 4 centre (11, 15): the last cell, clipped bottom-right
+        [47.9, 63.9, 1],            # 5 centre (12, 16): one cell off the map -> weight 0, as the
+                                    #   reference leaves such a joint's heat map empty
+        [-2.1, 10.0, 1],            # 6 centre -1: off the map although its window is not
+        [60.0, 10.0, 1],            # 7 centre 15 -> weight 0
         [20.0, 24.0, 0],            # 8 invisible
         [float("nan"), 5.0, 1],     # 9 not finite
         [20.0, float("inf"), 1],    # 10 not finite
         [20.0, 24.0, -1],           # 11 negative visibility counts as not visible
     ]], F32)
     t, w = oracle.render_targets(j, H, W, stride, sigma, r)
-    assert w[0].tolist() == [1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0, 0]
+    assert w[0].tolist() == [1, 1, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0]
     g = oracle.gaussian_table(sigma, r)
     assert t[0, 0, 6, 5] == 1.0 and t[0, 0, 6, 8] == g[3] and t[0, 0, 6, 9] == 0
     assert t[0, 0, 9, 8] == F32(g[3] * g[3])
     assert np.argmax(t[0, 1]) == 6 * W + 5
     assert np.argmax(t[0, 2]) == 7 * W + 6
     assert t[0, 3, 0, 0] == 1.0 and np.count_nonzero(t[0, 3]) == 16
-    assert t[0, 4, H - 1, W - 1] == F32(g[1] * g[1]) and np.count_nonzero(t[0, 4]) == 9
-    assert np.count_nonzero(t[0, 5]) == 7 and t[0, 5, 3, 0] == g[3]
-    for k in range(6, 12):
+    assert t[0, 4, H - 1, W - 1] == 1.0 and np.count_nonzero(t[0, 4]) == 16
+    for k in range(5, 12):
         assert not t[0, k].any()
+
+
+# ------------------------------------------------------------------ vector maps
+def test_vecmaps_against_python_loops():
+    H, W, stride, r = 16, 12, 4.0, 2
+    pairs = [(0, 1), (2, 1), (3, 4)]
+    j = np.array([[[20.0, 24.0, 2], [9.0, 40.0, 1], [47.9, 63.9, 1], [20.0, 24.0, 0], [5.0, 5.0, 1]],
+                  [[-30.0, 8.0, 1], [2.0, 2.0, 1], [float("nan"), 1.0, 1], [1.0, 1.0, 1],
+                   [46.0, 60.0, 2]]], F32)
+    vec, sup = oracle.render_vecmaps(j, pairs, H, W, stride, r)
+    assert vec.shape == (2, 12, H, W) and sup.shape == vec.shape
+    for b in range(2):
+        for i, (k1, k2) in enumerate(pairs):
+            ok = all(j[b, k, 2] > 0 and np.isfinite(j[b, k, :2]).all() for k in (k1, k2))
+            for half, (ks, kd) in enumerate(((k1, k2), (k2, k1))):
+                for axis in range(2):
+                    c = 4 * i + 2 * half + axis
+                    for y in range(H):
+                        for x in range(W):
+                            want, inside = 0.0, False
+                            if ok:
+                                sx = math.floor(j[b, ks, 0] / stride + 0.5)
+                                sy = math.floor(j[b, ks, 1] / stride + 0.5)
+                                dx = math.floor(j[b, kd, 0] / stride + 0.5)
+                                dy = math.floor(j[b, kd, 1] / stride + 0.5)
+                                inside = abs(x - sx) <= r and abs(y - sy) <= r
+                                if inside:
+                                    want = (dy - y) if axis else (dx - x)
+                            assert vec[b, c, y, x] == want and sup[b, c, y, x] == inside
+    assert not vec[0, 8:12].any()       # joint 3 is unlabelled: the whole pair is empty
+    assert not vec[1, 4:8].any()        # joint 2 is not finite
+    assert vec[1, 2:4].any() and not vec[1, 0:2].any()   # joint 0's window is wholly off the map
+
+
+def test_vecmap_loss_against_float64_and_finite_differences():
+    rng = np.random.default_rng(3)
+    B, H, W, stride, r = 2, 8, 8, 4.0, 1
+    pairs = [(0, 1), (1, 2)]
+    j = np.array([[[10.0, 12.0, 1], [20.0, 6.0, 1], [30.5, 30.5, 2]],
+                  [[4.0, 4.0, 1], [31.9, 0.0, 1], [8.0, 8.0, 0]]], F32)
+    p = rng.normal(size=(B, 8, H, W)).astype(F32)
+    m = (rng.uniform(size=(B, H, W)) > 0.2).astype(np.uint8)
+    t, sup = oracle.render_vecmaps(j, pairs, H, W, stride, r)
+    loss, pc, g = oracle.vecmap_loss_fwd_bwd(p, j, pairs, stride, r, m)
+
+    def loss64(pp):
+        keep = sup & (m[:, None] != 0)
+        return 0.5 * (((pp.astype(np.float64) - t) ** 2) * keep).sum() / pp.size
+
+    assert float(loss) == pytest.approx(loss64(p), rel=1e-6)
+    assert float(pc.mean()) == pytest.approx(float(loss), rel=1e-6)
+    assert not g[~sup].any() and g[sup & (m[:, None] != 0)].any()
+    for idx in [(0, 0, 3, 2), (0, 5, 1, 5), (1, 2, 0, 7), (1, 0, 1, 1), (0, 7, 7, 7)]:
+        e = np.zeros_like(p, dtype=np.float64)
+        e[idx] = 1e-3
+        fd = (loss64(p + e) - loss64(p - e)) / 2e-3
+        assert g[idx] == pytest.approx(fd, rel=1e-3, abs=1e-9)
+    # bf16 predictions: gradient rounds to bf16, loss uses the widened values
+    pb = oracle.f32_to_bf16_bits(p)
+    lb, _, gb = oracle.vecmap_loss_fwd_bwd(pb, j, pairs, stride, r, m, pred_is_bf16=True)
+    assert float(lb) == pytest.approx(loss64(oracle.bf16_bits_to_f32(pb)), rel=1e-6)
+    assert gb.dtype == np.uint16
 
 
 # ------------------------------------------------------------------ loss

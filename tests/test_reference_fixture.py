@@ -1,10 +1,17 @@
 """The only results the reference pins for this path: outputs printed by its notebook.
 
 tests/golden/reference_notebook_fixture.json holds the non-zero index lists of one 40x40x3
-heat-map label (test.ipynb:606-614): five 3x3 blocks.  The label is multi-person (two
-instances share channels 0 and 1), so the instances are rendered as separate (person, joint)
-maps and merged with an element-wise maximum; radius 1 at stride 8 must reproduce the support
-exactly.  Values are not pinned by the reference beyond "in (0, 1]" (test.ipynb:922).
+heat-map label (test.ipynb:606-614): five 3x3 blocks, and of the 40x40x8 vector-map label of
+the same sample (test.ipynb:634-653): 116 entries.  The label is multi-person (two instances
+share channels 0 and 1), so the instances are rendered as separate (person, joint) maps and
+merged (maximum for heat maps, sum for the disjoint vector maps); radius 1 at stride 8 must
+reproduce both supports exactly.  Heat-map values are not pinned by the reference beyond
+"in (0, 1]" (test.ipynb:922); vector-map values are pinned through their zero pattern (an offset
+component equal to 0 is missing from the non-zero list), which fixes every centre.
+
+The vector map shows a third joint of the second person whose centre is one column past the
+right edge (row 19, column 40): its vector-map window survives clipped to column 39, and the
+partner's entries point at the off-map centre, while heat-map channel 2 holds nothing there.
 """
 import json
 
@@ -107,3 +114,63 @@ def test_hip_render_reproduces_reference_support_nhwc(fixture):
     oxy, oconf, oidx = oracle.decode_heatmaps(want)
     assert np.array_equal(idx.cpu().numpy(), oidx)
     assert np.array_equal(xy.cpu().numpy(), oxy)
+
+
+# ------------------------------------------------------------------ vector maps
+PAIRS = [(0, 1), (2, 1)]          # the reference's drawing cell: pairs = [[0, 1], [2, 1]]
+
+
+def two_person_joints(stride):
+    """Both persons of the label with all three joints; person 1's joint 2 sits at (19, 40)."""
+    def px(r, c):
+        return (c * stride + 1.5, r * stride - 2.5, 2)
+
+    j = np.zeros((2, 3, 3), np.float32)
+    j[0, 0], j[0, 1], j[0, 2] = px(5, 18), px(6, 15), px(12, 18)
+    j[1, 0], j[1, 1], j[1, 2] = px(13, 38), px(19, 38), px(19, 40)
+    return j
+
+
+def assert_vec_support(label_hwc, fix):
+    rows, cols, chans = label_hwc.nonzero()
+    nz = fix["vecmaps_nonzero"]
+    assert rows.tolist() == nz["rows"]
+    assert cols.tolist() == nz["cols"]
+    assert chans.tolist() == nz["channels"]
+
+
+def test_oracle_vecmaps_reproduce_reference_support(fixture):
+    H, W, K = fixture["heatmap_shape_hwc"]
+    j = two_person_joints(fixture["stride"])
+    vec, sup = oracle.render_vecmaps(j, PAIRS, H, W, fixture["stride"], radius=1)
+    assert len(fixture["vecmaps_nonzero"]["rows"]) == 116
+    assert_vec_support(vec.sum(axis=0).transpose(1, 2, 0), fixture)
+    # the same joints give the heat-map support too: the off-map joint is labelled but not drawn
+    t, w = oracle.render_targets(j, H, W, fixture["stride"], sigma=1.0, radius=1)
+    assert w.tolist() == [[1, 1, 1], [1, 1, 0]]
+    rows, cols, chans = t.max(axis=0).transpose(1, 2, 0).nonzero()
+    assert rows.tolist() == fixture["heatmaps_nonzero"]["rows"]
+    assert cols.tolist() == fixture["heatmaps_nonzero"]["cols"]
+    assert chans.tolist() == fixture["heatmaps_nonzero"]["channels"]
+    # offsets follow the drawing cell's reading: cell + (vec[4i], vec[4i+1]) is the partner's centre
+    ys, xs = np.nonzero(sup[0, 0])
+    assert set((y + int(vec[0, 1, y, x]), x + int(vec[0, 0, y, x])) for y, x in zip(ys, xs)) == {(6, 15)}
+
+
+@pytest.mark.gpu
+def test_hip_vecmaps_reproduce_reference_support_nhwc(fixture):
+    import torch
+
+    from pose_estimation_amd import ops
+
+    H, W, K = fixture["heatmap_shape_hwc"]
+    j = two_person_joints(fixture["stride"])
+    jt = torch.from_numpy(j).cuda()
+    v_nhwc = ops.render_vecmaps(jt, PAIRS, H, W, fixture["stride"], radius=1, layout="NHWC")
+    assert v_nhwc.shape == (2, H, W, 8)
+    assert_vec_support(v_nhwc.sum(dim=0).cpu().numpy(), fixture)
+    want, _ = oracle.render_vecmaps(j, PAIRS, H, W, fixture["stride"], radius=1)
+    assert np.array_equal(v_nhwc.permute(0, 3, 1, 2).cpu().numpy(), want)
+    assert np.array_equal(ops.render_vecmaps(jt, PAIRS, H, W, fixture["stride"], 1).cpu().numpy(), want)
+    t, w = ops.render_targets(jt, H, W, fixture["stride"], sigma=1.0, radius=1)
+    assert w.cpu().tolist() == [[1, 1, 1], [1, 1, 0]]
