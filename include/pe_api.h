@@ -279,6 +279,20 @@ int32_t pe_stem7x7s2_bwd_weight_bf16(int32_t B, int32_t H2, int32_t W2, int32_t 
 int32_t pe_transpose_weights_bf16(const void* in, int32_t A, int32_t T, int32_t C, void* out,
                                   int32_t slots, int32_t apitch, int32_t t0, pe_stream_t stream);
 
+/* The same transpose for many weights in one launch.  jobs_device: DEVICE array of njobs
+ * records; tile_begin is the running sum of T * ceil(A/64) * ceil(C/64) over the jobs before
+ * it (ascending), total_tiles the sum over all jobs. */
+typedef struct pe_transpose_job {
+    const void* in;   /* [A][T][C] bf16 */
+    void* out;        /* [C][slots][apitch] bf16 */
+    int32_t A, T, C, slots, apitch, t0;
+    int32_t tile_begin;
+    int32_t reserved;
+} pe_transpose_job;
+
+int32_t pe_transpose_weights_batched_bf16(const pe_transpose_job* jobs_device, int32_t njobs,
+                                          int32_t total_tiles, pe_stream_t stream);
+
 /* Loss-gradient hand-over: float32 [B][K][HW] -> bf16 [B*HW][Kpad] (zero padded), and
  * dbias[k] += sum over pixels (dbias may be NULL; the caller zeroes it). */
 int32_t pe_final_grad_prepare_bf16(const float* g_nchw, int32_t B, int32_t K, int32_t HW,

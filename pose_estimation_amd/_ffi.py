@@ -121,6 +121,7 @@ SIGNATURES = {
         c_int32,
         [c_void_p, c_int32, c_int32, c_int32, c_void_p, c_int32, c_int32, c_int32, c_void_p],
     ),
+    "pe_transpose_weights_batched_bf16": (c_int32, [c_void_p, c_int32, c_int32, c_void_p]),
     "pe_final_grad_prepare_bf16": (
         c_int32, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p],
     ),

@@ -35,6 +35,48 @@ __global__ __launch_bounds__(256) void transpose_w_kernel(const uint16_t* __rest
     }
 }
 
+// The same transpose for a whole table of weights in one launch (a training step re-packs
+// about 70 small tensors; one launch each would be launch-latency bound).  Workgroup b works
+// on tile b - tile_begin of the job whose tile range holds b.
+__global__ __launch_bounds__(256) void transpose_w_batched_kernel(const pe_transpose_job* __restrict__ jobs,
+                                                                  int njobs) {
+    __shared__ uint16_t tile[64][66];
+    __shared__ int job_s;
+    if (threadIdx.x == 0) {
+        int lo = 0, hi = njobs - 1;  // last job with tile_begin <= blockIdx.x
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (jobs[mid].tile_begin <= (int)blockIdx.x) lo = mid;
+            else hi = mid - 1;
+        }
+        job_s = lo;
+    }
+    __syncthreads();
+    const pe_transpose_job jb = jobs[job_s];
+    const int A = jb.A, T = jb.T, C = jb.C;
+    const int ntc = (C + 63) / 64, nta = (A + 63) / 64;
+    int local = blockIdx.x - jb.tile_begin;
+    const int t = local / (ntc * nta);
+    if (t >= T) return;  // uniform
+    local -= t * ntc * nta;
+    const int a0 = (local / ntc) * 64;
+    const int c0 = (local % ntc) * 64;
+    const uint16_t* in = static_cast<const uint16_t*>(jb.in);
+    uint16_t* out = static_cast<uint16_t*>(jb.out);
+    const int tx = threadIdx.x & 63;
+    const int ty = threadIdx.x >> 6;
+    for (int r = ty; r < 64; r += 4) {
+        const int a = a0 + r, c = c0 + tx;
+        tile[r][tx] = (a < A && c < C) ? in[((long)a * T + t) * C + c] : (uint16_t)0;
+    }
+    __syncthreads();
+    for (int r = ty; r < 64; r += 4) {
+        const int c = c0 + r, a = a0 + tx;
+        if (c < C && a < A)
+            out[(long)c * jb.slots * jb.apitch + (long)(jb.t0 + t) * jb.apitch + a] = tile[tx][r];
+    }
+}
+
 // Max-pool 3x3/2 pad 1 backward in gather form: an input cell receives the gradient of every
 // window whose FIRST maximum (scan order ky, kx) it is - the same tie rule as an arg-max pool.
 __global__ __launch_bounds__(256) void maxpool3x3s2_bwd_kernel(const uint16_t* __restrict__ x,
@@ -417,6 +459,16 @@ extern "C" int32_t pe_transpose_weights_bf16(const void* in, int32_t A, int32_t 
     transpose_w_kernel<<<grid, 256, 0, as_stream(stream)>>>(
         static_cast<const uint16_t*>(in), A, T, C, static_cast<uint16_t*>(out), slots, apitch, t0);
     return check_launch("pe_transpose_weights_bf16");
+}
+
+extern "C" int32_t pe_transpose_weights_batched_bf16(const pe_transpose_job* jobs_device,
+                                                     int32_t njobs, int32_t total_tiles,
+                                                     pe_stream_t stream) {
+    PE_REQUIRE(jobs_device != nullptr && njobs > 0 && total_tiles > 0, PE_E_INVALID,
+               "pe_transpose_weights_batched_bf16: empty job table");
+    transpose_w_batched_kernel<<<(unsigned)total_tiles, 256, 0, as_stream(stream)>>>(jobs_device,
+                                                                                    njobs);
+    return check_launch("pe_transpose_weights_batched_bf16");
 }
 
 extern "C" int32_t pe_maxpool3x3s2_bwd_bf16(const void* x, const void* dy, int32_t B, int32_t H,

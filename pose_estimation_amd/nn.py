@@ -10,6 +10,7 @@ from __future__ import annotations
 import ctypes
 from typing import Optional
 
+import numpy as np
 import torch
 
 from ._ffi import ConvDesc, check, lib
@@ -181,6 +182,47 @@ def transpose_weights(w: torch.Tensor, out: torch.Tensor, t0: int = 0) -> torch.
         check(lib().pe_transpose_weights_bf16(w.data_ptr(), A, T, C, out.data_ptr(), slots, apitch,
                                               t0, _stream(w)))
     return out
+
+
+class TransposePlan:
+    """A fixed list of weight transposes (see transpose_weights) executed as one launch.
+    The tensors must stay alive and in place for the life of the plan."""
+
+    _DTYPE = np.dtype([("in", np.uint64), ("out", np.uint64), ("A", np.int32), ("T", np.int32),
+                       ("C", np.int32), ("slots", np.int32), ("apitch", np.int32),
+                       ("t0", np.int32), ("tile_begin", np.int32), ("reserved", np.int32)])
+
+    def __init__(self, device):
+        self.device = device
+        self._jobs = []
+        self._table = None
+        self._tiles = 0
+
+    def add(self, w: torch.Tensor, out: torch.Tensor, t0: int = 0) -> None:
+        _need_gpu(w, out)
+        A, T, C = w.shape
+        if w.dtype != BF16 or out.dtype != BF16 or not w.is_contiguous() or not out.is_contiguous():
+            raise ValueError("transpose operands must be contiguous bfloat16")
+        if out.shape[0] != C or out.shape[1] < t0 + T or out.shape[2] < A:
+            raise ValueError(f"transpose output {tuple(out.shape)} too small for {tuple(w.shape)}")
+        self._jobs.append((w.data_ptr(), out.data_ptr(), A, T, C, out.shape[1], out.shape[2], t0))
+        self._table = None
+
+    def run(self) -> None:
+        if not self._jobs:
+            return
+        if self._table is None:
+            rec = np.zeros(len(self._jobs), dtype=self._DTYPE)
+            tiles = 0
+            for i, (src, dst, A, T, C, slots, apitch, t0) in enumerate(self._jobs):
+                rec[i] = (src, dst, A, T, C, slots, apitch, t0, tiles, 0)
+                tiles += T * ((A + 63) // 64) * ((C + 63) // 64)
+            self._tiles = tiles
+            self._table = torch.from_numpy(rec.view(np.uint8)).to(self.device)
+        with torch.cuda.device(self.device):
+            check(lib().pe_transpose_weights_batched_bf16(
+                self._table.data_ptr(), len(self._jobs), self._tiles,
+                torch.cuda.current_stream(self.device).cuda_stream))
 
 
 def conv2d_bwd_data(dy: torch.Tensor, w_t: torch.Tensor, in_hw, k: int, stride: int, pad: int,

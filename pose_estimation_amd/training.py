@@ -47,6 +47,7 @@ class TrainablePoseResNet(PoseResNet):
         self.bn_buf = {c.name: torch.empty(4, c.cout, dtype=torch.float32, device=dev)
                        for c in self.convs if c.bn}
         self._ws: Optional[torch.Tensor] = None
+        self._tplan = None
         stem = self.specs[0]
         self.stem_mask = pnn.pack_stem_weight(torch.ones(stem.cout, 3, 7, 7)).float().to(dev)
         # layer start offsets in arena order (a layer = weight + its BN / bias vectors)
@@ -74,15 +75,20 @@ class TrainablePoseResNet(PoseResNet):
         self.refresh_transposes()
 
     def refresh_transposes(self) -> None:
-        for c in self.convs:
-            w = self.w(c)
-            if c.kind == "conv":
-                pnn.transpose_weights(w.view(c.cout, c.k * c.k, c.cin), self.wt[c.name])
-            elif c.kind == "deconv":
-                for ph in range(4):
-                    pnn.transpose_weights(w[ph], self.wt[c.name], t0=4 * ph)
-            elif c.kind == "final":
-                pnn.transpose_weights(w.view(c.cout, 1, c.cin), self.wt[c.name])
+        """Re-packs every weight for the backward-data GEMMs (one launch for all layers)."""
+        if self._tplan is None:
+            plan = pnn.TransposePlan(self.work.device)
+            for c in self.convs:
+                w = self.w(c)
+                if c.kind == "conv":
+                    plan.add(w.view(c.cout, c.k * c.k, c.cin), self.wt[c.name])
+                elif c.kind == "deconv":
+                    for ph in range(4):
+                        plan.add(w[ph], self.wt[c.name], t0=4 * ph)
+                elif c.kind == "final":
+                    plan.add(w.view(c.cout, 1, c.cin), self.wt[c.name])
+            self._tplan = plan
+        self._tplan.run()
 
     def _workspace(self, z: torch.Tensor) -> torch.Tensor:
         C = z.shape[3]
