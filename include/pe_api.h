@@ -234,14 +234,16 @@ int32_t pe_preprocess_u8_s2d_bf16(const uint8_t* img, int32_t B, int32_t H, int3
                                   const float* mean3, const float* std3, void* x_s2d,
                                   pe_stream_t stream);
 
-/* 3x3 stride-2 pad-1 max pool, NHWC bf16: [B,H,W,C] -> [B,H/2,W/2,C] (H, W even; C % 8 == 0). */
+/* 3x3 stride-2 pad-1 max pool, NHWC bf16: [B,H,W,C] -> [B,H/2,W/2,C] (H, W even; C % 8 == 0).
+ * idx (may be NULL; training passes it): uint8 [B,H/2,W/2,C], the window position ky*3+kx of
+ * each output's first maximum in row-major scan order. */
 int32_t pe_maxpool3x3s2_fwd_bf16(const void* x, int32_t B, int32_t H, int32_t W, int32_t C,
-                                 void* y, pe_stream_t stream);
+                                 void* y, uint8_t* idx, pe_stream_t stream);
 
-/* Backward of the pool above: dx [B,H,W,C] from x [B,H,W,C] and dy [B,H/2,W/2,C]; a tie inside
- * a window sends the gradient to its first maximum (row-major scan). */
-int32_t pe_maxpool3x3s2_bwd_bf16(const void* x, const void* dy, int32_t B, int32_t H, int32_t W,
-                                 int32_t C, void* dx, pe_stream_t stream);
+/* Backward of the pool above: dx [B,H,W,C] from the forward pass's idx and dy [B,H/2,W/2,C];
+ * a tie inside a window sends the gradient to its first maximum (row-major scan). */
+int32_t pe_maxpool3x3s2_bwd_bf16(const uint8_t* idx, const void* dy, int32_t B, int32_t H,
+                                 int32_t W, int32_t C, void* dx, pe_stream_t stream);
 
 /* Backward-data.  d describes the FORWARD conv (stride 1 or 2); dy is [B,Ho,Wo,Cout] bf16;
  * w_t is the transposed weight [Cin][KH*KW][Cout] bf16 (see pe_transpose_weights_bf16);

@@ -91,7 +91,7 @@ SIGNATURES = {
         [c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p],
     ),
     "pe_maxpool3x3s2_fwd_bf16": (
-        c_int32, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p],
+        c_int32, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p],
     ),
     "pe_maxpool3x3s2_bwd_bf16": (
         c_int32, [c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p],

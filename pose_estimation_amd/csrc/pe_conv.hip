@@ -47,10 +47,13 @@ __global__ __launch_bounds__(256) void preprocess_s2d_kernel(const uint8_t* __re
     out[2 * t + 1] = make_uint4(o[4], o[5], o[6], o[7]);
 }
 
-// 3x3 stride-2 pad-1 max pool over NHWC bf16; one thread per 8 output channels.
+// 3x3 stride-2 pad-1 max pool over NHWC bf16; one thread per 8 output channels.  With `idx`
+// it also records, per output element, the window position ky*3+kx of the FIRST maximum in
+// scan order, which is all the backward pass needs.
 __global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const uint16_t* __restrict__ x, int B,
                                                            int H, int W, int C,
-                                                           uint16_t* __restrict__ y) {
+                                                           uint16_t* __restrict__ y,
+                                                           uint8_t* __restrict__ idx) {
     const int Ho = H / 2, Wo = W / 2, C8 = C / 8;
     const long total = (long)B * Ho * Wo * C8;
     const long t = (long)blockIdx.x * 256 + threadIdx.x;
@@ -62,8 +65,12 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const uint16_t* __res
     const int oy = (int)(r % Ho);
     const long b = r / Ho;
     float best[8];
+    uint32_t pos[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) best[i] = -INFINITY;
+    for (int i = 0; i < 8; ++i) {
+        best[i] = -INFINITY;
+        pos[i] = 255u;
+    }
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky) {
         const int iy = oy * 2 - 1 + ky;
@@ -74,12 +81,25 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const uint16_t* __res
             if ((unsigned)ix >= (unsigned)W) continue;
             const uint4 v = *reinterpret_cast<const uint4*>(x + ((b * H + iy) * W + ix) * C + c8 * 8);
             const uint32_t u[4] = {v.x, v.y, v.z, v.w};
+            float f[8];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                best[2 * i] = fmaxf(best[2 * i], bf16_bits_to_float(u[i] & 0xffffu));
-                best[2 * i + 1] = fmaxf(best[2 * i + 1], bf16_bits_to_float(u[i] >> 16));
+                f[2 * i] = bf16_bits_to_float(u[i] & 0xffffu);
+                f[2 * i + 1] = bf16_bits_to_float(u[i] >> 16);
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                // strictly greater keeps the first maximum; the first valid cell always enters
+                if (f[i] > best[i] || pos[i] == 255u) pos[i] = (uint32_t)(ky * 3 + kx);
+                best[i] = fmaxf(best[i], f[i]);
             }
         }
+    }
+    if (idx) {
+        uint2 pk;
+        pk.x = pos[0] | (pos[1] << 8) | (pos[2] << 16) | (pos[3] << 24);
+        pk.y = pos[4] | (pos[5] << 8) | (pos[6] << 16) | (pos[7] << 24);
+        *reinterpret_cast<uint2*>(idx + ((b * Ho + oy) * Wo + ox) * (long)C + c8 * 8) = pk;
     }
     uint4 o;
     o.x = float_to_bf16_bits(best[0]) | (float_to_bf16_bits(best[1]) << 16);
@@ -237,13 +257,15 @@ extern "C" int32_t pe_preprocess_u8_s2d_bf16(const uint8_t* img, int32_t B, int3
 }
 
 extern "C" int32_t pe_maxpool3x3s2_fwd_bf16(const void* x, int32_t B, int32_t H, int32_t W,
-                                            int32_t C, void* y, pe_stream_t stream) {
+                                            int32_t C, void* y, uint8_t* idx,
+                                            pe_stream_t stream) {
     PE_REQUIRE(x && y, PE_E_INVALID, "pe_maxpool3x3s2_fwd_bf16: NULL pointer");
     PE_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && H % 2 == 0 && W % 2 == 0 && C % 8 == 0,
                PE_E_UNSUPPORTED, "pe_maxpool3x3s2_fwd_bf16: need even H, W and C %% 8 == 0");
-    PE_REQUIRE(aligned(x, 16) && aligned(y, 16), PE_E_INVALID, "pe_maxpool3x3s2_fwd_bf16: misaligned");
+    PE_REQUIRE(aligned(x, 16) && aligned(y, 16) && aligned(idx, 8), PE_E_INVALID,
+               "pe_maxpool3x3s2_fwd_bf16: misaligned");
     const long total = (long)B * (H / 2) * (W / 2) * (C / 8);
     maxpool3x3s2_kernel<<<(unsigned)((total + 255) / 256), 256, 0, as_stream(stream)>>>(
-        static_cast<const uint16_t*>(x), B, H, W, C, static_cast<uint16_t*>(y));
+        static_cast<const uint16_t*>(x), B, H, W, C, static_cast<uint16_t*>(y), idx);
     return check_launch("pe_maxpool3x3s2_fwd_bf16");
 }

@@ -78,12 +78,13 @@ __global__ __launch_bounds__(256) void transpose_w_batched_kernel(const pe_trans
 }
 
 // Max-pool 3x3/2 pad 1 backward in gather form: an input cell receives the gradient of every
-// window whose FIRST maximum (scan order ky, kx) it is - the same tie rule as an arg-max pool.
-__global__ __launch_bounds__(256) void maxpool3x3s2_bwd_kernel(const uint16_t* __restrict__ x,
+// window whose recorded first-maximum position (idx = ky*3+kx, written by the forward pass) is
+// that cell.  Reads idx and dy of at most four windows per cell; never touches x.
+__global__ __launch_bounds__(256) void maxpool3x3s2_bwd_kernel(const uint8_t* __restrict__ idx,
                                                                const uint16_t* __restrict__ dy,
                                                                int B, int H, int W, int C,
                                                                uint16_t* __restrict__ dx) {
-    // one thread per 8 channels of one input cell, 16-byte accesses
+    // one thread per 8 channels of one input cell, 16-byte stores
     const int Ho = H / 2, Wo = W / 2, C8 = C / 8;
     const long total = (long)B * H * W * C8;
     for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
@@ -93,53 +94,26 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_bwd_kernel(const uint16_t* _
         r /= W;
         const int iy = (int)(r % H);
         const long b = r / H;
-        float v[8], g[8];
-        {
-            const uint4 xv = *reinterpret_cast<const uint4*>(x + e * 8);
-            const uint32_t u[4] = {xv.x, xv.y, xv.z, xv.w};
+        float g[8];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                v[2 * i] = bf16_bits_to_float(u[i] & 0xffffu);
-                v[2 * i + 1] = bf16_bits_to_float(u[i] >> 16);
-                g[2 * i] = g[2 * i + 1] = 0.0f;
-            }
-        }
+        for (int i = 0; i < 8; ++i) g[i] = 0.0f;
         // windows (oy, ox) with oy*2-1 <= iy <= oy*2+1
         for (int oy = iy / 2; oy <= (iy + 1) / 2; ++oy) {
             if (oy >= Ho) continue;
             for (int ox = ix / 2; ox <= (ix + 1) / 2; ++ox) {
                 if (ox >= Wo) continue;
-                // per channel: is (iy, ix) the first maximum of this window?
-                bool first[8];
-#pragma unroll
-                for (int i = 0; i < 8; ++i) first[i] = true;
-                for (int ky = 0; ky < 3; ++ky) {
-                    const int yy = oy * 2 - 1 + ky;
-                    if ((unsigned)yy >= (unsigned)H) continue;
-                    for (int kx = 0; kx < 3; ++kx) {
-                        const int xx = ox * 2 - 1 + kx;
-                        if ((unsigned)xx >= (unsigned)W) continue;
-                        const bool before = (yy < iy) || (yy == iy && xx < ix);
-                        const uint4 nv = *reinterpret_cast<const uint4*>(
-                            x + (((b * H + yy) * W + xx) * (long)C8 + c8) * 8);
-                        const uint32_t u[4] = {nv.x, nv.y, nv.z, nv.w};
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            const float lo = bf16_bits_to_float(u[i] & 0xffffu);
-                            const float hi = bf16_bits_to_float(u[i] >> 16);
-                            if (lo > v[2 * i] || (before && lo == v[2 * i])) first[2 * i] = false;
-                            if (hi > v[2 * i + 1] || (before && hi == v[2 * i + 1]))
-                                first[2 * i + 1] = false;
-                        }
-                    }
-                }
-                const uint4 dv = *reinterpret_cast<const uint4*>(
-                    dy + (((b * Ho + oy) * Wo + ox) * (long)C8 + c8) * 8);
+                const uint32_t me = (uint32_t)((iy - (oy * 2 - 1)) * 3 + (ix - (ox * 2 - 1)));
+                const long o = (((b * Ho + oy) * Wo + ox) * (long)C8 + c8) * 8;
+                const uint2 pk = *reinterpret_cast<const uint2*>(idx + o);
+                const uint4 dv = *reinterpret_cast<const uint4*>(dy + o);
                 const uint32_t u[4] = {dv.x, dv.y, dv.z, dv.w};
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    if (first[2 * i]) g[2 * i] += bf16_bits_to_float(u[i] & 0xffffu);
-                    if (first[2 * i + 1]) g[2 * i + 1] += bf16_bits_to_float(u[i] >> 16);
+                    const uint32_t word = i < 2 ? pk.x : pk.y;
+                    const uint32_t p0 = (word >> (16 * (i & 1))) & 0xffu;
+                    const uint32_t p1 = (word >> (16 * (i & 1) + 8)) & 0xffu;
+                    if (p0 == me) g[2 * i] += bf16_bits_to_float(u[i] & 0xffffu);
+                    if (p1 == me) g[2 * i + 1] += bf16_bits_to_float(u[i] >> 16);
                 }
             }
         }
@@ -471,19 +445,19 @@ extern "C" int32_t pe_transpose_weights_batched_bf16(const pe_transpose_job* job
     return check_launch("pe_transpose_weights_batched_bf16");
 }
 
-extern "C" int32_t pe_maxpool3x3s2_bwd_bf16(const void* x, const void* dy, int32_t B, int32_t H,
-                                            int32_t W, int32_t C, void* dx, pe_stream_t stream) {
-    PE_REQUIRE(x && dy && dx, PE_E_INVALID, "pe_maxpool3x3s2_bwd_bf16: NULL pointer");
+extern "C" int32_t pe_maxpool3x3s2_bwd_bf16(const uint8_t* idx, const void* dy, int32_t B,
+                                            int32_t H, int32_t W, int32_t C, void* dx,
+                                            pe_stream_t stream) {
+    PE_REQUIRE(idx && dy && dx, PE_E_INVALID, "pe_maxpool3x3s2_bwd_bf16: NULL pointer");
     PE_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && H % 2 == 0 && W % 2 == 0 && C % 8 == 0,
                PE_E_UNSUPPORTED, "pe_maxpool3x3s2_bwd_bf16: need even H, W and C %% 8 == 0");
-    PE_REQUIRE(aligned(x, 16) && aligned(dy, 16) && aligned(dx, 16), PE_E_INVALID,
-               "pe_maxpool3x3s2_bwd_bf16: tensors must be 16-byte aligned");
+    PE_REQUIRE(aligned(idx, 8) && aligned(dy, 16) && aligned(dx, 16), PE_E_INVALID,
+               "pe_maxpool3x3s2_bwd_bf16: tensors must be 16-byte aligned (idx: 8)");
     const long total = (long)B * H * W * (C / 8);
     long blocks = (total + 255) / 256;
     if (blocks > 256 * 32) blocks = 256 * 32;
     maxpool3x3s2_bwd_kernel<<<(unsigned)blocks, 256, 0, as_stream(stream)>>>(
-        static_cast<const uint16_t*>(x), static_cast<const uint16_t*>(dy), B, H, W, C,
-        static_cast<uint16_t*>(dx));
+        idx, static_cast<const uint16_t*>(dy), B, H, W, C, static_cast<uint16_t*>(dx));
     return check_launch("pe_maxpool3x3s2_bwd_bf16");
 }
 

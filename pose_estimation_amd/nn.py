@@ -159,14 +159,19 @@ def preprocess_u8(img: torch.Tensor, mean=IMAGENET_MEAN, std=IMAGENET_STD,
     return out
 
 
-def maxpool3x3s2(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+def maxpool3x3s2(x: torch.Tensor, out: Optional[torch.Tensor] = None, want_index: bool = False):
+    """3x3/2 max pool.  With want_index also returns the uint8 first-maximum positions the
+    backward pass reads: (y, idx)."""
     _check_act(x)
     B, H, W, C = x.shape
     if out is None:
         out = torch.empty((B, H // 2, W // 2, C), dtype=BF16, device=x.device)
+    idx = torch.empty((B, H // 2, W // 2, C), dtype=torch.uint8, device=x.device) if want_index \
+        else None
     with torch.cuda.device(x.device):
-        check(lib().pe_maxpool3x3s2_fwd_bf16(x.data_ptr(), B, H, W, C, out.data_ptr(), _stream(x)))
-    return out
+        check(lib().pe_maxpool3x3s2_fwd_bf16(x.data_ptr(), B, H, W, C, out.data_ptr(), _ptr(idx),
+                                             _stream(x)))
+    return (out, idx) if want_index else out
 
 
 # --------------------------------------------------------------------------- backward
@@ -318,16 +323,19 @@ def stem7x7s2_bwd_weight(x_s2d: torch.Tensor, dy: torch.Tensor, dw: torch.Tensor
                                                  _stream(x_s2d)))
 
 
-def maxpool3x3s2_bwd(x: torch.Tensor, dy: torch.Tensor,
+def maxpool3x3s2_bwd(idx: torch.Tensor, dy: torch.Tensor,
                      out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    _check_act(x)
+    """dx [B,2Ho,2Wo,C] from the forward pass's idx and dy [B,Ho,Wo,C]."""
     _check_act(dy, "dy")
-    B, H, W, C = x.shape
+    _need_gpu(idx)
+    if idx.dtype != torch.uint8 or tuple(idx.shape) != tuple(dy.shape) or not idx.is_contiguous():
+        raise ValueError("idx must be a contiguous uint8 tensor shaped like dy")
+    B, Ho, Wo, C = dy.shape
     if out is None:
-        out = torch.empty_like(x)
-    with torch.cuda.device(x.device):
-        check(lib().pe_maxpool3x3s2_bwd_bf16(x.data_ptr(), dy.data_ptr(), B, H, W, C,
-                                             out.data_ptr(), _stream(x)))
+        out = torch.empty((B, 2 * Ho, 2 * Wo, C), dtype=BF16, device=dy.device)
+    with torch.cuda.device(dy.device):
+        check(lib().pe_maxpool3x3s2_bwd_bf16(idx.data_ptr(), dy.data_ptr(), B, 2 * Ho, 2 * Wo, C,
+                                             out.data_ptr(), _stream(dy)))
     return out
 
 

@@ -172,8 +172,8 @@ class TrainablePoseResNet(PoseResNet):
         xs = pnn.preprocess_u8(images_u8)
         z0 = pnn.stem7x7s2(xs, self.w(stem), None, None, relu=False)
         a0 = self._bn(stem, z0)
-        x = pnn.maxpool3x3s2(a0)
-        sv.update(xs=xs, z0=z0, a0=a0)
+        x, pool_idx = pnn.maxpool3x3s2(a0, want_index=True)
+        sv.update(xs=xs, z0=z0, a0=a0, pool_idx=pool_idx)
         for b in blocks:
             s = self.block_forward(b, x)
             sv["blocks"].append(s)
@@ -217,7 +217,7 @@ class TrainablePoseResNet(PoseResNet):
         for b, s in zip(reversed(blocks), reversed(sv["blocks"])):
             dx = self.block_backward(b, s, dx)
         # stem
-        da0 = pnn.maxpool3x3s2_bwd(sv["a0"], dx)
+        da0 = pnn.maxpool3x3s2_bwd(sv["pool_idx"], dx)
         dz0, _ = self._bn_bwd(stem, da0, sv["a0"], sv["z0"])
         gw = self._g(stem.name + ".weight")
         pnn.stem7x7s2_bwd_weight(sv["xs"], dz0, gw)

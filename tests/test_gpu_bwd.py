@@ -232,5 +232,8 @@ def test_maxpool_backward_with_ties():
     dy = rnd((3, 8, 6, 64), g)
     xt = nchw(x).requires_grad_(True)
     F.max_pool2d(xt, 3, 2, 1).backward(nchw(dy))
-    got = pnn.maxpool3x3s2_bwd(x.to(BF16).cuda(), dy.to(BF16).cuda())
+    y, idx = pnn.maxpool3x3s2(x.to(BF16).cuda(), want_index=True)
+    assert torch.equal(y.float().cpu(), nhwc(F.max_pool2d(nchw(x), 3, 2, 1)))
+    assert idx.dtype == torch.uint8 and int(idx.max()) <= 8
+    got = pnn.maxpool3x3s2_bwd(idx, dy.to(BF16).cuda())
     close(got.float().cpu(), nhwc(xt.grad), 4e-3)  # sums of up to 4 bf16 values, rounded once
