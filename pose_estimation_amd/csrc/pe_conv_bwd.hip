@@ -157,21 +157,39 @@ __global__ __launch_bounds__(256) void final_grad_prepare_kernel(const float* __
     }
 }
 
-// dbias[k] += sum over images and pixels of g[b][k][:], one workgroup per k, summed in a fixed
-// order (thread-strided partials, wave shuffle tree, waves in order): bit-stable.
-__global__ __launch_bounds__(256) void bias_grad_kernel(const float* __restrict__ g, int B, int K,
-                                                        int HW, float* __restrict__ dbias) {
-    __shared__ float red[4];
+// dbias[k] += sum over images and pixels of g[b][k][:], one 1024-thread workgroup per k, summed
+// in a fixed order (thread-strided 16-byte partials, wave shuffle tree, waves in order).
+__global__ __launch_bounds__(1024) void bias_grad_kernel(const float* __restrict__ g, int B, int K,
+                                                         int HW, float* __restrict__ dbias) {
+    __shared__ float red[16];
     const int k = blockIdx.x;
     float s = 0.0f;
-    for (int b = 0; b < B; ++b) {
-        const float* plane = g + ((long)b * K + k) * HW;
-        for (int i = threadIdx.x; i < HW; i += 256) s += plane[i];
+    if ((HW & 3) == 0) {
+        const int hw4 = HW >> 2;
+        const long n4 = (long)B * hw4;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+        for (long j = threadIdx.x; j < n4; j += 1024) {
+            const long b = j / hw4;
+            const int off = (int)(j - b * hw4);
+            acc += __builtin_nontemporal_load(
+                reinterpret_cast<const f32x4*>(g + (b * K + k) * (long)HW) + off);
+        }
+        s = (acc.x + acc.y) + (acc.z + acc.w);
+    } else {
+        for (int b = 0; b < B; ++b) {
+            const float* plane = g + ((long)b * K + k) * HW;
+            for (int i = threadIdx.x; i < HW; i += 1024) s += plane[i];
+        }
     }
     s = wave_sum(s);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) dbias[k] += ((red[0] + red[1]) + red[2]) + red[3];
+    if (threadIdx.x == 0) {
+        float t = 0.0f;
+        for (int w = 0; w < 16; ++w) t += red[w];
+        dbias[k] += t;
+    }
 }
 
 __global__ __launch_bounds__(256) void mul_f32_kernel(float* __restrict__ a,
@@ -475,7 +493,7 @@ extern "C" int32_t pe_final_grad_prepare_bf16(const float* g_nchw, int32_t B, in
         g_nchw, npix, K, HW, Kpad, static_cast<uint16_t*>(out_nhwc));
     const int32_t rc = check_launch("pe_final_grad_prepare_bf16");
     if (rc != PE_OK || dbias == nullptr) return rc;
-    bias_grad_kernel<<<(unsigned)K, 256, 0, as_stream(stream)>>>(g_nchw, B, K, HW, dbias);
+    bias_grad_kernel<<<(unsigned)K, 1024, 0, as_stream(stream)>>>(g_nchw, B, K, HW, dbias);
     return check_launch("pe_final_grad_prepare_bf16 (bias)");
 }
 

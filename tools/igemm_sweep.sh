@@ -1,8 +1,9 @@
 #!/bin/bash
 # Forces each implicit-GEMM tile configuration in turn: conv parity tests, then layer timings.
-# usage: tools/igemm_sweep.sh "cfg1 cfg2 ..."   (cfg = BM,BN,WM,DB,PF,MINB; "default" = launcher's choice)
+# usage: tools/igemm_sweep.sh "cfg1 cfg2 ..." ["shape1 shape2 ..."]
+#   cfg = BM,BN,WM,DB,PF,MINB; "default" = launcher's choice
 set -u
-SHAPES="256,16,12,256,256,3 256,32,24,128,128,3 256,64,48,64,64,3 256,8,6,512,512,3 256,64,48,64,256,1 256,64,48,256,64,1 256,16,12,1024,256,1"
+SHAPES=${2:-"256,16,12,256,256,3 256,32,24,128,128,3 256,64,48,64,64,3 256,8,6,512,512,3 256,64,48,64,256,1 256,64,48,256,64,1 256,16,12,1024,256,1"}
 for cfg in $1; do
     echo "== cfg $cfg"
     if [ "$cfg" != default ]; then export PE_IGEMM_CFG=$cfg; fi
