@@ -174,3 +174,31 @@ def test_hip_vecmaps_reproduce_reference_support_nhwc(fixture):
     assert np.array_equal(ops.render_vecmaps(jt, PAIRS, H, W, fixture["stride"], 1).cpu().numpy(), want)
     t, w = ops.render_targets(jt, H, W, fixture["stride"], sigma=1.0, radius=1)
     assert w.cpu().tolist() == [[1, 1, 1], [1, 1, 0]]
+
+
+def test_oracle_vecmap_values_match_the_notebooks_printed_offsets(fixture):
+    """The drawing cell prints (vecmaps[y, x, 4i], vecmaps[y, x, 4i+1]) over the first joint's
+    cells in row-major order, nine per 3x3 instance (135 value pairs in all).  Each block of
+    nine must be what the oracle renders for a partner at the offset the block's centre
+    names; an all-zero block is an instance whose partner joint is unlabelled."""
+    H, W, K = fixture["heatmap_shape_hwc"]
+    stride = fixture["stride"]
+    total = 0
+    for group in fixture["vecmap_printed_values"]:
+        k1, k2 = group["pair"]
+        i = PAIRS.index((k1, k2))
+        vals = group["values"]
+        assert len(vals) % 9 == 0
+        for n in range(0, len(vals), 9):
+            block = np.array(vals[n:n + 9], np.float32)
+            ox, oy = int(block[4, 0]), int(block[4, 1])
+            j = np.zeros((1, K, 3), np.float32)
+            j[0, k1] = (20 * stride + 1.5, 20 * stride - 2.5, 2)
+            if block.any():
+                j[0, k2] = ((20 + ox) * stride + 1.5, (20 + oy) * stride - 2.5, 2)
+            vec, sup = oracle.render_vecmaps(j, PAIRS, H, W, stride, radius=1)
+            got = np.stack([vec[0, 4 * i, 19:22, 19:22].reshape(-1),
+                            vec[0, 4 * i + 1, 19:22, 19:22].reshape(-1)], axis=1)
+            assert np.array_equal(got, block), (group["pair"], n)
+            total += 9
+    assert total == 135
