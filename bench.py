@@ -300,6 +300,56 @@ class Infer(Workload):
                 "sample": f"torch-CPU float32 oracle forward, batch 8, median of 3 ({med:.2f} s)"}
 
 
+class MobileNetInfer(Workload):
+    """The reference's own backbone family and resolution: MobileNetV2 (output stride 8) +
+    heat-map head, 320x320 images -> 40x40 maps, batch 256, bf16, preprocessing and decode
+    included.  Mostly bandwidth-bound (depthwise 3x3 and thin pointwise layers)."""
+    name = "mobilenetv2_pose_infer_320x320_b256_bf16"
+    batch = 256
+    heatmap = (40, 40)
+    dtype = "bf16"
+    bound = "mfma"
+    kernel = "igemm_kernel + depthwise3x3_kernel (all launches of one forward)"
+    peak = 2500.0
+
+    def setup(self, device):
+        from pose_estimation_amd import mobilenet as mb
+
+        self.net = mb.PoseMobileNetV2(device)
+        self.net.load_state(mb.init_state(self.net.blocks, seed=3))
+        self.flops_per_step = 2.0 * mb.forward_macs(320, 320, K_JOINTS) * self.batch
+        self.imgs = [torch.from_numpy(synthetic.images_u8(self.batch, 320, 320, seed=1 + i)).to(device)
+                     for i in range(2)]
+
+    def step(self, i):
+        pe.decode(self.net.predict(self.imgs[i % 2]))
+
+    def roofline(self, kern_ms):
+        ach = self.flops_per_step / (kern_ms * 1e-3) / 1e12
+        return {"bound": "mfma", "kernel": self.kernel, "achieved": ach, "peak": self.peak,
+                "unit": "TFLOP/s", "frac": ach / self.peak,
+                "flops_per_step": self.flops_per_step, "step_ms": kern_ms, "traffic": None}
+
+    def cpu_baseline(self):
+        from oracle import torch_oracle as to
+        from pose_estimation_amd import mobilenet as mb
+        from pose_estimation_amd import nn as pnn
+
+        blocks = mb.mobilenet_v2_specs()
+        state = mb.init_state(blocks, seed=3)
+        img = synthetic.images_u8(8, 320, 320, seed=1)
+        to.mobilenet_pose_forward(blocks, state, img[:1], pnn.IMAGENET_MEAN, pnn.IMAGENET_STD)
+        times = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            to.mobilenet_pose_forward(blocks, state, img, pnn.IMAGENET_MEAN, pnn.IMAGENET_STD)
+            times.append(time.perf_counter() - t0)
+        med = float(np.median(times))
+        return {"value": 8 / med, "unit": "images/s", "cores": torch.get_num_threads(),
+                "kind": "port",
+                "sample": f"torch-CPU float32 oracle forward, batch 8, median of 3 ({med:.2f} s)"}
+
+
 class Train(Workload):
     """BASELINE configs[3]: full training step (forward with batch statistics, fused target
     render + masked MSE, backward, gradient all-reduce when N > 1, fused Adam), batch 64 per GPU."""
@@ -362,7 +412,7 @@ class Train(Workload):
 
 
 WORKLOADS = {"decode": Decode, "render": Render, "mse": Mse, "mse_fused": MseFused, "adam": Adam,
-             "vecmap": VecRender, "vecmap_loss": VecLoss,
+             "vecmap": VecRender, "vecmap_loss": VecLoss, "mobilenet": MobileNetInfer,
              "infer": Infer, "train": Train}
 
 
@@ -449,7 +499,7 @@ def main() -> None:
             "dtype": wl.dtype,
             "data": "synthetic",
             "config": {"workload": wl.name, "batch_per_gpu": wl.batch, "joints": K_JOINTS,
-                       "heatmap": [H, W],
+                       "heatmap": list(getattr(wl, "heatmap", (H, W))),
                        "sharding": getattr(wl, "sharding", "batch, no collective")},
             "roofline": roof,
         }

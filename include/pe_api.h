@@ -229,6 +229,25 @@ int32_t pe_stem7x7s2_fwd_bf16(int32_t B, int32_t H2, int32_t W2, int32_t Cout, i
                               const void* x_s2d, const void* w, const float* scale,
                               const float* shift, void* y, pe_stream_t stream);
 
+/* 3x3 stride-2 pad-1 stem on a 3-channel image (MobileNetV2's first conv; the reference's
+ * backbone, nets/mobilenet_v2.py, PoseEstimation.pyproj:32, absent), computed over the same
+ * space-to-depth image as a 2-row conv: w [Cout][2 rows][4 cols x 16] bf16 (columns 2, 3 zero),
+ * x_s2d [B,H/2,W/2,16] -> y [B,H/2,W/2,Cout].  relu: 0 none, 1 ReLU, 2 ReLU6 (also accepted by
+ * every conv entry above). */
+int32_t pe_stem3x3s2_fwd_bf16(int32_t B, int32_t H2, int32_t W2, int32_t Cout, int32_t relu,
+                              const void* x_s2d, const void* w, const float* scale,
+                              const float* shift, void* y, pe_stream_t stream);
+
+/* Depthwise 3x3 conv, NHWC bf16, stride 1 or 2, dilation >= 1, pad = dilation:
+ * y[b,oy,ox,c] = act(scale[c] * sum_{ky,kx} w[ky*3+kx][c] * x[b, oy*s+(ky-1)*d, ox*s+(kx-1)*d, c]
+ *                    + shift[c]);  w is [9][C] bf16, scale/shift float32 [C] or NULL,
+ * y [B, (H-1)/s+1, (W-1)/s+1, C].  C % 8 == 0.  Replaces the depthwise layers of the
+ * reference's nets/mobilenet_v2.py (absent). */
+int32_t pe_depthwise3x3_fwd_bf16(const void* x, int32_t B, int32_t H, int32_t W, int32_t C,
+                                 int32_t stride, int32_t dilation, const void* w,
+                                 const float* scale, const float* shift, int32_t relu, void* y,
+                                 pe_stream_t stream);
+
 /* uint8 RGB [B,H,W,3] -> (x/255 - mean[c]) / std[c] -> bf16 space-to-depth [B,H/2,W/2,16]. */
 int32_t pe_preprocess_u8_s2d_bf16(const uint8_t* img, int32_t B, int32_t H, int32_t W,
                                   const float* mean3, const float* std3, void* x_s2d,

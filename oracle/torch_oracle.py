@@ -136,6 +136,62 @@ def pose_resnet_forward(specs, state, img_u8: np.ndarray, mean, std, bn_eps: flo
     return y.permute(0, 3, 1, 2).contiguous()
 
 
+def depthwise3x3(x_nhwc, w_c133, scale=None, shift=None, stride=1, dilation=1, relu6=True,
+                 acc64=False):
+    """Depthwise 3x3, pad = dilation; w in torch layout [C,1,3,3]."""
+    C = x_nhwc.shape[3]
+    if acc64:
+        y = F.conv2d(_nchw(x_nhwc).double(), w_c133.double(), None, stride=stride,
+                     padding=dilation, dilation=dilation, groups=C).float()
+    else:
+        y = F.conv2d(_nchw(x_nhwc), w_c133, None, stride=stride, padding=dilation,
+                     dilation=dilation, groups=C)
+    if scale is not None:
+        y = y * scale.view(1, -1, 1, 1)
+    if shift is not None:
+        y = y + shift.view(1, -1, 1, 1)
+    y = _nhwc(y)
+    return torch.clamp(y, 0.0, 6.0) if relu6 else y
+
+
+def mobilenet_pose_forward(blocks, state, img_u8: np.ndarray, mean, std, bn_eps: float = 1e-5,
+                           acc64: bool = False, with_vec: bool = False):
+    """Inference forward of the MobileNetV2 pose net on the CPU (true channel counts, no
+    padding), float32 accumulation, operands rounded to bf16 where the kernels store bf16: the
+    weights, the preprocessed image and every layer output except the heads' float32 maps.
+
+    blocks: pose_estimation_amd.mobilenet.mobilenet_v2_specs(...) (plain dataclasses).
+    Returns heat maps [B,K,h,w] (and vector maps when with_vec)."""
+    def fold(name):
+        sc = state[name + ".bn.gamma"] / torch.sqrt(state[name + ".bn.var"] + bn_eps)
+        return sc, state[name + ".bn.beta"] - state[name + ".bn.mean"] * sc
+
+    def relu6(t):
+        return torch.clamp(t, 0.0, 6.0)
+
+    x = torch.from_numpy(preprocess_u8(img_u8, mean, std))
+    sc, sh = fold("stem")
+    x = bf16r(relu6(conv2d(x, bf16r(state["stem.weight"]), sc, sh, None, 2, 1, acc64=acc64)))
+    for b in blocks:
+        h = x
+        if b.expand != 1:
+            sc, sh = fold(b.name + ".expand")
+            h = bf16r(relu6(conv2d(h, bf16r(state[b.name + ".expand.weight"]), sc, sh,
+                                   acc64=acc64)))
+        sc, sh = fold(b.name + ".dw")
+        h = bf16r(depthwise3x3(h, bf16r(state[b.name + ".dw.weight"]), sc, sh, b.stride,
+                               b.dilation, True, acc64=acc64))
+        sc, sh = fold(b.name + ".project")
+        x = bf16r(conv2d(h, bf16r(state[b.name + ".project.weight"]), sc, sh,
+                         x if b.residual else None, acc64=acc64))
+    heat = conv2d(x, bf16r(state["heat.weight"]), None, state["heat.bias"], acc64=acc64)
+    heat = heat.permute(0, 3, 1, 2).contiguous()
+    if not with_vec:
+        return heat
+    vec = conv2d(x, bf16r(state["vec.weight"]), None, state["vec.bias"], acc64=acc64)
+    return heat, vec.permute(0, 3, 1, 2).contiguous()
+
+
 # ----------------------------------------------------------------------------------------------
 # Training step: forward with batch statistics, masked MSE against rendered targets, autograd.
 # ----------------------------------------------------------------------------------------------

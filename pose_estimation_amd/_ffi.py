@@ -86,6 +86,16 @@ SIGNATURES = {
         [c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p,
          c_void_p, c_void_p],
     ),
+    "pe_stem3x3s2_fwd_bf16": (
+        c_int32,
+        [c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p,
+         c_void_p, c_void_p],
+    ),
+    "pe_depthwise3x3_fwd_bf16": (
+        c_int32,
+        [c_void_p, c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p,
+         c_void_p, c_int32, c_void_p, c_void_p],
+    ),
     "pe_preprocess_u8_s2d_bf16": (
         c_int32,
         [c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p],

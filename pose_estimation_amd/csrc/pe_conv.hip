@@ -241,6 +241,41 @@ extern "C" int32_t pe_stem7x7s2_fwd_bf16(int32_t B, int32_t H2, int32_t W2, int3
     return igemm_launch(p, as_stream(stream), "pe_stem7x7s2_fwd_bf16");
 }
 
+extern "C" int32_t pe_stem3x3s2_fwd_bf16(int32_t B, int32_t H2, int32_t W2, int32_t Cout,
+                                         int32_t relu, const void* x_s2d, const void* w,
+                                         const float* scale, const float* shift, void* y,
+                                         pe_stream_t stream) {
+    PE_REQUIRE(B > 0 && H2 > 0 && W2 > 0 && Cout > 0, PE_E_INVALID,
+               "pe_stem3x3s2_fwd_bf16: sizes must be positive");
+    IgemmParams p;
+    base_params(p);
+    p.x = static_cast<const uint16_t*>(x_s2d);
+    p.w = static_cast<const uint16_t*>(w);
+    p.y = y;
+    p.scale = scale;
+    p.shift = shift;
+    p.B = B;
+    p.Hi = H2;
+    p.Wi = W2;
+    p.Cx = 16;
+    p.Cin = 64;   // one tap = one row of the 2x2 footprint, padded to 4 pixels x 16 channels
+    p.cshift = 4;
+    p.cmask = 15;
+    p.Ho = H2;
+    p.Wo = W2;
+    p.N = Cout;
+    p.T = 2;
+    for (int r = 0; r < 2; ++r) {
+        p.tap_dy[r] = (int16_t)(r - 1);
+        p.tap_dx[r] = -1;
+    }
+    p.OH = H2;
+    p.OW = W2;
+    p.ldc = Cout;
+    p.relu = relu;
+    return igemm_launch(p, as_stream(stream), "pe_stem3x3s2_fwd_bf16");
+}
+
 extern "C" int32_t pe_preprocess_u8_s2d_bf16(const uint8_t* img, int32_t B, int32_t H, int32_t W,
                                              const float* mean3, const float* std3, void* x_s2d,
                                              pe_stream_t stream) {

@@ -36,7 +36,7 @@ struct IgemmParams {
     int wk_row;             // weight row length in elements (0 = T*Cin, taps packed densely)
     int OH, OW, osy, osx, ooy, oox;  // output scatter
     int ldc;                // output channels per pixel (bf16 NHWC) / unused for f32 NCHW
-    int relu;
+    int relu;               // 0: none   1: ReLU   2: ReLU6
     int out_mode;           // 0: bf16 NHWC   1: f32 NCHW [B][N][OH*OW]
     int16_t tap_dy[kMaxTaps];
     int16_t tap_dx[kMaxTaps];

@@ -311,6 +311,10 @@ __attribute__((amdgpu_waves_per_eu(MINB * WM / 2, MINB * WM / 2))) void igemm_ke
                     if (p.relu) {
 #pragma unroll
                         for (int i = 0; i < 8; ++i) v[i] = fmaxf(v[i], 0.0f);
+                        if (p.relu == 2) {  // ReLU6
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) v[i] = fminf(v[i], 6.0f);
+                        }
                     }
                     uint4 o;
                     o.x = pack_bf16x2(v[0], v[1]);
@@ -345,9 +349,11 @@ __attribute__((amdgpu_waves_per_eu(MINB * WM / 2, MINB * WM / 2))) void igemm_ke
                 if (p.out_mode == 0) {
                     if (p.res) t += bf16_bits_to_float(p.res[opix * p.ldc + n + j]);
                     if (p.relu) t = fmaxf(t, 0.0f);
+                    if (p.relu == 2) t = fminf(t, 6.0f);
                     reinterpret_cast<uint16_t*>(p.y)[opix * p.ldc + n + j] = (uint16_t)float_to_bf16_bits(t);
                 } else {
                     if (p.relu) t = fmaxf(t, 0.0f);
+                    if (p.relu == 2) t = fminf(t, 6.0f);
                     reinterpret_cast<float*>(p.y)[((long)bb * p.N + n + j) * OHW + opl] = t;
                 }
             }

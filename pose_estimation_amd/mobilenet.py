@@ -1,0 +1,196 @@
+"""MobileNetV2 pose network (inference) on the HIP kernels: the backbone family the reference
+names (nets/mobilenet_v2.py, model/mobilenet_pose.py; PoseEstimation.pyproj:31-32, both absent)
+at the resolution its notebook uses: 320x320 images, stride-8 label maps of 40x40
+(test.ipynb:919, 1010).
+
+Architecture (the public MobileNetV2-1.0 definition, no reference source to follow): 3x3/2 stem
+to 32 channels, 17 inverted-residual blocks (t, c, n, s) = (1,16,1,1) (6,24,2,2) (6,32,3,2)
+(6,64,4,2) (6,96,3,1) (6,160,3,2) (6,320,1,1), every conv followed by BN and ReLU6 except the
+linear 1x1 projections.  Once the running stride reaches `output_stride` (8) later strides
+become dilation, so the feature map stays 40x40 at 320x320.  Heads: a 1x1 conv to K heat maps
+and, optionally, a 1x1 conv to 4 channels per keypoint pair (vector maps); float32 NCHW outputs.
+
+Layout: activations NHWC bf16 with every channel count padded up to a multiple of 64 (the
+implicit-GEMM K step); padded weights, scales and shifts are zero, so padded channels stay zero
+through ReLU6 and the linear projections.  The pointwise convs run on the MFMA engine
+(pe_conv2d_fwd_bf16), the depthwise convs on the bandwidth-bound pe_depthwise3x3_fwd_bf16.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Dict, List, Optional
+
+import torch
+
+from . import nn as pnn
+from . import ops
+
+BF16 = torch.bfloat16
+BN_EPS = 1e-5
+MBV2_SETTING = [(1, 16, 1, 1), (6, 24, 2, 2), (6, 32, 3, 2), (6, 64, 4, 2), (6, 96, 3, 1),
+                (6, 160, 3, 2), (6, 320, 1, 1)]
+
+
+def pad64(c: int) -> int:
+    return (c + 63) // 64 * 64
+
+
+@dataclass
+class MBBlock:
+    name: str
+    cin: int
+    cout: int
+    expand: int          # expansion factor t (1 = no expansion conv)
+    stride: int
+    dilation: int
+    residual: bool
+
+    @property
+    def mid(self) -> int:
+        return self.cin * self.expand
+
+
+def mobilenet_v2_specs(output_stride: int = 8, setting=None, stem_ch: int = 32) -> List[MBBlock]:
+    blocks: List[MBBlock] = []
+    cin, cur, dil = stem_ch, 2, 1
+    for si, (t, c, n, s) in enumerate(setting or MBV2_SETTING):
+        for i in range(n):
+            stride = s if i == 0 else 1
+            d = dil
+            if stride == 2 and cur >= output_stride:
+                stride, dil = 1, dil * 2   # the stride turns into dilation of the layers after it
+            elif stride == 2:
+                cur *= 2
+            blocks.append(MBBlock(f"block{len(blocks)}", cin, c, t, stride, d,
+                                  stride == 1 and cin == c))
+            cin = c
+    return blocks
+
+
+def forward_macs(H: int = 320, W: int = 320, num_joints: int = 17, num_pairs: int = 0,
+                 output_stride: int = 8, setting=None) -> int:
+    """Multiply-accumulates of one forward at the true (unpadded) channel counts."""
+    blocks = mobilenet_v2_specs(output_stride, setting)
+    h, w = H // 2, W // 2
+    macs = h * w * 27 * 32
+    for b in blocks:
+        if b.expand != 1:
+            macs += h * w * b.cin * b.mid
+        h, w = (h - 1) // b.stride + 1, (w - 1) // b.stride + 1
+        macs += h * w * 9 * b.mid + h * w * b.mid * b.cout
+    macs += h * w * blocks[-1].cout * (num_joints + 4 * num_pairs)
+    return macs
+
+
+def init_state(blocks: List[MBBlock], num_joints: int = 17, num_pairs: int = 0,
+               seed: int = 3, stem_ch: int = 32) -> Dict[str, torch.Tensor]:
+    """Random-init state dict in framework layouts (CPU float32): He-normal convs (fan-out),
+    BN gamma 1 / beta 0 / running (0, 1), heads N(0, 0.01) with zero bias."""
+    g = torch.Generator().manual_seed(seed)
+    st: Dict[str, torch.Tensor] = {}
+
+    def conv(name, cout, cin, k, groups=1):
+        fan_out = cout * k * k // groups
+        st[name + ".weight"] = torch.randn((cout, cin // groups, k, k), generator=g) * (2.0 / fan_out) ** 0.5
+        st[name + ".bn.gamma"] = torch.ones(cout)
+        st[name + ".bn.beta"] = torch.zeros(cout)
+        st[name + ".bn.mean"] = torch.zeros(cout)
+        st[name + ".bn.var"] = torch.ones(cout)
+
+    conv("stem", stem_ch, 3, 3)
+    for b in blocks:
+        if b.expand != 1:
+            conv(b.name + ".expand", b.mid, b.cin, 1)
+        conv(b.name + ".dw", b.mid, b.mid, 3, groups=b.mid)
+        conv(b.name + ".project", b.cout, b.mid, 1)
+    cf = blocks[-1].cout
+    st["heat.weight"] = torch.randn((num_joints, cf, 1, 1), generator=g) * 0.01
+    st["heat.bias"] = torch.zeros(num_joints)
+    if num_pairs:
+        st["vec.weight"] = torch.randn((4 * num_pairs, cf, 1, 1), generator=g) * 0.01
+        st["vec.bias"] = torch.zeros(4 * num_pairs)
+    return st
+
+
+class PoseMobileNetV2:
+    """MobileNetV2 backbone + heat-map (and vector-map) heads on one GPU, inference only."""
+
+    def __init__(self, device, num_joints: int = 17, num_pairs: int = 0, output_stride: int = 8,
+                 setting=None):
+        self.device = torch.device(device)
+        self.num_joints = num_joints
+        self.num_pairs = num_pairs
+        self.blocks = mobilenet_v2_specs(output_stride, setting)
+        self.output_stride = output_stride
+        self.p: Dict[str, torch.Tensor] = {}
+
+    # ------------------------------------------------------------------ parameters
+    def _fold(self, st, name, cout_pad):
+        sc = st[name + ".bn.gamma"] / torch.sqrt(st[name + ".bn.var"] + BN_EPS)
+        sh = st[name + ".bn.beta"] - st[name + ".bn.mean"] * sc
+        scp = torch.zeros(cout_pad)
+        shp = torch.zeros(cout_pad)
+        scp[:sc.numel()] = sc
+        shp[:sh.numel()] = sh
+        self.p[name + ".scale"] = scp.to(self.device)
+        self.p[name + ".shift"] = shp.to(self.device)
+
+    def _pointwise(self, st, name, cin, cout, fold=True):
+        w = torch.zeros(pad64(cout) if fold else cout, 1, 1, pad64(cin))
+        w[:cout, 0, 0, :cin] = st[name + ".weight"][:, :, 0, 0]
+        self.p[name + ".weight"] = w.to(BF16).to(self.device)
+        if fold:
+            self._fold(st, name, pad64(cout))
+        else:
+            self.p[name + ".bias"] = st[name + ".bias"].float().to(self.device)
+
+    def load_state(self, st: Dict[str, torch.Tensor]) -> None:
+        self.p.clear()
+        self.p["stem.weight"] = torch.zeros(64, 2, 64, dtype=BF16)
+        self.p["stem.weight"][:st["stem.weight"].shape[0]] = pnn.pack_stem3x3_weight(st["stem.weight"])
+        self.p["stem.weight"] = self.p["stem.weight"].to(self.device)
+        self._fold(st, "stem", 64)
+        for b in self.blocks:
+            if b.expand != 1:
+                self._pointwise(st, b.name + ".expand", b.cin, b.mid)
+            w = torch.zeros(9, pad64(b.mid))
+            w[:, :b.mid] = st[b.name + ".dw.weight"][:, 0].reshape(b.mid, 9).t()
+            self.p[b.name + ".dw.weight"] = w.to(BF16).contiguous().to(self.device)
+            self._fold(st, b.name + ".dw", pad64(b.mid))
+            self._pointwise(st, b.name + ".project", b.mid, b.cout)
+        cf = self.blocks[-1].cout
+        self._pointwise(st, "heat", cf, self.num_joints, fold=False)
+        if self.num_pairs:
+            self._pointwise(st, "vec", cf, 4 * self.num_pairs, fold=False)
+
+    # ------------------------------------------------------------------ inference
+    def forward_features(self, x_s2d: torch.Tensor) -> torch.Tensor:
+        p = self.p
+        x = pnn.stem3x3s2(x_s2d, p["stem.weight"], p["stem.scale"], p["stem.shift"], relu=2)
+        for b in self.blocks:
+            h = x
+            if b.expand != 1:
+                n = b.name + ".expand"
+                h = pnn.conv2d(h, p[n + ".weight"], p[n + ".scale"], p[n + ".shift"], relu=2)
+            n = b.name + ".dw"
+            h = pnn.depthwise3x3(h, p[n + ".weight"], p[n + ".scale"], p[n + ".shift"],
+                                 stride=b.stride, dilation=b.dilation, relu=2)
+            n = b.name + ".project"
+            x = pnn.conv2d(h, p[n + ".weight"], p[n + ".scale"], p[n + ".shift"],
+                           residual=x if b.residual else None, relu=0)
+        return x
+
+    def predict(self, images_u8: torch.Tensor):
+        """uint8 [B,H,W,3] -> heat maps float32 [B,K,H/8,W/8] (and vector maps [B,4P,H/8,W/8]
+        when the model has a vector-map head: returns (heat, vec))."""
+        if not self.p:
+            raise RuntimeError("load_state() has not been called")
+        f = self.forward_features(pnn.preprocess_u8(images_u8))
+        heat = pnn.conv2d(f, self.p["heat.weight"], None, self.p["heat.bias"], out_f32_nchw=True)
+        if not self.num_pairs:
+            return heat
+        vec = pnn.conv2d(f, self.p["vec.weight"], None, self.p["vec.bias"], out_f32_nchw=True)
+        return heat, vec
+
+    def decode(self, heatmaps: torch.Tensor):
+        return ops.decode(heatmaps)

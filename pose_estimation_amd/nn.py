@@ -142,6 +142,55 @@ IMAGENET_MEAN = (0.485, 0.456, 0.406)
 IMAGENET_STD = (0.229, 0.224, 0.225)
 
 
+def pack_stem3x3_weight(w_oihw: torch.Tensor) -> torch.Tensor:
+    """3x3 stride-2 pad-1 stem weight [Cout,3,3,3] -> bf16 [Cout, 2 rows, 4 cols * 16] for the
+    equivalent 2-row conv over the 2x2 space-to-depth image (channel = (ry*2+rx)*3+c).  Kernel
+    row ky reads s2d row offset (ky+1)//2 - 1 at parity (ky+1) % 2, and likewise for columns."""
+    cout = w_oihw.shape[0]
+    out = torch.zeros(cout, 2, 4, 16, dtype=torch.float32)
+    for ky in range(3):
+        r, ry = (ky + 1) // 2, (ky + 1) % 2
+        for kx in range(3):
+            q, rx = (kx + 1) // 2, (kx + 1) % 2
+            s = (ry * 2 + rx) * 3
+            out[:, r, q, s:s + 3] = w_oihw[:, :, ky, kx]
+    return out.reshape(cout, 2, 64).contiguous().to(BF16)
+
+
+def stem3x3s2(x_s2d: torch.Tensor, w: torch.Tensor, scale=None, shift=None, relu: int = 2,
+              out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """3x3/2 stem on the space-to-depth image: x_s2d [B,H/2,W/2,16] -> [B,H/2,W/2,Cout]."""
+    _check_act(x_s2d, "x_s2d")
+    B, H2, W2, c16 = x_s2d.shape
+    if c16 != 16 or tuple(w.shape[1:]) != (2, 64) or w.dtype != BF16:
+        raise ValueError("stem3x3s2 expects x_s2d [B,H/2,W/2,16] and w bf16 [Cout,2,64]")
+    Cout = w.shape[0]
+    if out is None:
+        out = torch.empty((B, H2, W2, Cout), dtype=BF16, device=x_s2d.device)
+    with torch.cuda.device(x_s2d.device):
+        check(lib().pe_stem3x3s2_fwd_bf16(B, H2, W2, Cout, int(relu), x_s2d.data_ptr(),
+                                          w.data_ptr(), _ptr(scale), _ptr(shift), out.data_ptr(),
+                                          _stream(x_s2d)))
+    return out
+
+
+def depthwise3x3(x: torch.Tensor, w9c: torch.Tensor, scale=None, shift=None, stride: int = 1,
+                 dilation: int = 1, relu: int = 2, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Depthwise 3x3 conv with pad = dilation.  x [B,H,W,C] bf16, w9c [9,C] bf16."""
+    _check_act(x)
+    B, H, W, C = x.shape
+    if w9c.dtype != BF16 or tuple(w9c.shape) != (9, C) or not w9c.is_contiguous():
+        raise ValueError("depthwise weight must be contiguous bfloat16 [9, C]")
+    Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
+    if out is None:
+        out = torch.empty((B, Ho, Wo, C), dtype=BF16, device=x.device)
+    with torch.cuda.device(x.device):
+        check(lib().pe_depthwise3x3_fwd_bf16(x.data_ptr(), B, H, W, C, int(stride), int(dilation),
+                                             w9c.data_ptr(), _ptr(scale), _ptr(shift), int(relu),
+                                             out.data_ptr(), _stream(x)))
+    return out
+
+
 def preprocess_u8(img: torch.Tensor, mean=IMAGENET_MEAN, std=IMAGENET_STD,
                   out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """uint8 [B,H,W,3] -> normalised bf16 space-to-depth [B,H/2,W/2,16]."""
