@@ -2,9 +2,13 @@
 // dilation, "same" padding (pad = dilation), with folded-BN scale/shift and ReLU / ReLU6.
 //
 // Bound: HBM bandwidth.  9 MACs per element against 4 bytes of traffic, so there is nothing
-// for the matrix cores here: one thread owns 8 channels of one output pixel, every access is
-// 16 bytes, the nine input rows of a pixel's neighbourhood come from L1/L2 after their first
-// use, and the [9][C] weight block stays cache resident.  float32 accumulation in tap order.
+// for the matrix cores here; accumulation is float32 in tap order.  Stride 1 (15 of
+// MobileNetV2's 17 layers): a thread owns 4 channels of a 2 x 4 block of outputs taken
+// `dilation` apart, so the 4 x 6 inputs it loads serve 8 outputs (3 cache reads per output
+// instead of 9) and the nine weight vectors are loaded once.  Stride 2: 8 channels of one
+// output pixel per thread, 16-byte accesses.  No load sits behind a branch: out-of-image taps
+// read a valid address and are zeroed, so all of a thread's loads are in flight together.
+
 #include "pe_common.h"
 
 namespace pe {
@@ -37,20 +41,29 @@ __global__ __launch_bounds__(256) void depthwise3x3_kernel(const uint16_t* __res
         float acc[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) acc[i] = 0.0f;
+        // out-of-image taps load a valid address and contribute exact zeros, so the nine loads
+        // carry no branches and are all in flight together
+        uint4 xv[9];
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
             const int iy = oy * stride + (ky - 1) * dil;
-            if ((unsigned)iy >= (unsigned)H) continue;
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx) {
                 const int ix = ox * stride + (kx - 1) * dil;
-                if ((unsigned)ix >= (unsigned)W) continue;
-                float xf[8], wf[8];
-                dw_unpack(*reinterpret_cast<const uint4*>(x + (((b * H + iy) * W + ix) * (long)C8 + c8) * 8), xf);
-                dw_unpack(*reinterpret_cast<const uint4*>(w + ((long)(ky * 3 + kx) * C8 + c8) * 8), wf);
-#pragma unroll
-                for (int i = 0; i < 8; ++i) acc[i] += xf[i] * wf[i];
+                const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+                const long off = ok ? (((b * H + iy) * W + ix) * (long)C8 + c8) * 8 : (long)c8 * 8;
+                uint4 v = *reinterpret_cast<const uint4*>(x + off);
+                if (!ok) v = make_uint4(0u, 0u, 0u, 0u);
+                xv[ky * 3 + kx] = v;
             }
+        }
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            float xf[8], wf[8];
+            dw_unpack(xv[t], xf);
+            dw_unpack(*reinterpret_cast<const uint4*>(w + ((long)t * C8 + c8) * 8), wf);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] += xf[i] * wf[i];
         }
         if (scale) {
             const f32x4 s0 = *reinterpret_cast<const f32x4*>(scale + c8 * 8);
@@ -83,6 +96,113 @@ __global__ __launch_bounds__(256) void depthwise3x3_kernel(const uint16_t* __res
     }
 }
 
+// Stride-1 kernel.  Outputs are grouped by residue (oy % d, ox % d); within a residue class the
+// pixels d apart form a dense lattice, and a thread takes a 2 x 4 block of that lattice for FOUR
+// channels (8-byte accesses: the accumulators, the nine widened weights and a row of inputs fit
+// in about 100 registers, so five waves per SIMD stay resident).  Threads are ordered
+// channel-group fastest, so a wave reads and writes 512 contiguous bytes of a pixel.
+constexpr int DW_TY = 2, DW_TX = 4;
+
+__device__ __forceinline__ void dw_unpack4(const uint2& v, float* f) {
+    f[0] = bf16_bits_to_float(v.x & 0xffffu);
+    f[1] = bf16_bits_to_float(v.x >> 16);
+    f[2] = bf16_bits_to_float(v.y & 0xffffu);
+    f[3] = bf16_bits_to_float(v.y >> 16);
+}
+
+__global__ __launch_bounds__(256) void depthwise3x3_s1_kernel(const uint16_t* __restrict__ x, int B,
+                                                              int H, int W, int C, int dil,
+                                                              const uint16_t* __restrict__ w,
+                                                              const float* __restrict__ scale,
+                                                              const float* __restrict__ shift,
+                                                              int relu, uint16_t* __restrict__ y,
+                                                              int nty, int ntx) {
+    const int C4 = C >> 2;
+    const long total = (long)B * nty * ntx * C4;
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= total) return;
+    const int c4 = (int)(e % C4);
+    long r = e / C4;
+    const int tx = (int)(r % ntx);
+    r /= ntx;
+    const int ty = (int)(r % nty);
+    const long b = r / nty;
+    const int rx = tx % dil, X0 = (tx / dil) * DW_TX;
+    const int ry = ty % dil, Y0 = (ty / dil) * DW_TY;
+
+    float wf[9][4];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+        dw_unpack4(*reinterpret_cast<const uint2*>(w + ((long)t * C4 + c4) * 4), wf[t]);
+    float acc[DW_TY][DW_TX][4];
+#pragma unroll
+    for (int a = 0; a < DW_TY; ++a)
+#pragma unroll
+        for (int c = 0; c < DW_TX; ++c)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[a][c][i] = 0.0f;
+
+    // out-of-image inputs load a valid address and become zeros: no branches around the loads,
+    // so a row of six is in flight at once
+    const uint16_t* xb = x + (b * H * (long)W * C4 + c4) * 4;
+#pragma unroll
+    for (int j = 0; j < DW_TY + 2; ++j) {
+        const int iy = (Y0 + j - 1) * dil + ry;
+        uint2 xv[DW_TX + 2];
+#pragma unroll
+        for (int i = 0; i < DW_TX + 2; ++i) {
+            const int ix = (X0 + i - 1) * dil + rx;
+            const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+            uint2 v = *reinterpret_cast<const uint2*>(xb + (ok ? ((long)iy * W + ix) * C4 * 4 : 0L));
+            if (!ok) v = make_uint2(0u, 0u);
+            xv[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < DW_TX + 2; ++i) {
+            float xf[4];
+            dw_unpack4(xv[i], xf);
+#pragma unroll
+            for (int a = 0; a < DW_TY; ++a) {
+                const int ky = j - a;
+                if (ky < 0 || ky > 2) continue;
+#pragma unroll
+                for (int c = 0; c < DW_TX; ++c) {
+                    const int kx = i - c;
+                    if (kx < 0 || kx > 2) continue;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc[a][c][q] += xf[q] * wf[ky * 3 + kx][q];
+                }
+            }
+        }
+    }
+    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+    if (scale) sc = *reinterpret_cast<const f32x4*>(scale + c4 * 4);
+    if (shift) sh = *reinterpret_cast<const f32x4*>(shift + c4 * 4);
+    const float scf[4] = {sc.x, sc.y, sc.z, sc.w}, shf[4] = {sh.x, sh.y, sh.z, sh.w};
+#pragma unroll
+    for (int a = 0; a < DW_TY; ++a) {
+        const int oy = (Y0 + a) * dil + ry;
+#pragma unroll
+        for (int c = 0; c < DW_TX; ++c) {
+            const int ox = (X0 + c) * dil + rx;
+            if (oy >= H || ox >= W) continue;
+            float v[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                v[q] = acc[a][c][q];
+                if (scale) v[q] *= scf[q];
+                if (shift) v[q] += shf[q];
+                if (relu) v[q] = fmaxf(v[q], 0.0f);
+                if (relu == 2) v[q] = fminf(v[q], 6.0f);
+            }
+            uint2 o;
+            o.x = float_to_bf16_bits(v[0]) | (float_to_bf16_bits(v[1]) << 16);
+            o.y = float_to_bf16_bits(v[2]) | (float_to_bf16_bits(v[3]) << 16);
+            *reinterpret_cast<uint2*>(y + (((b * H + oy) * (long)W + ox) * C4 + c4) * 4) = o;
+        }
+    }
+}
+
 }  // namespace pe
 
 using namespace pe;
@@ -106,6 +226,17 @@ extern "C" int32_t pe_depthwise3x3_fwd_bf16(const void* x, int32_t B, int32_t H,
     const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
     const long total = (long)B * Ho * Wo * (C / 8);
     PE_REQUIRE((long)B * H * W * (C / 8) < (1L << 40), PE_E_UNSUPPORTED, "%s: tensor too large", what);
+    if (stride == 1) {
+        // lattice tiles per residue class, residues interleaved: nty = d * ceil(ceil(H/d) / 2)
+        const int nty = dilation * (((H + dilation - 1) / dilation + DW_TY - 1) / DW_TY);
+        const int ntx = dilation * (((W + dilation - 1) / dilation + DW_TX - 1) / DW_TX);
+        const long threads = (long)B * nty * ntx * (C / 4);
+        PE_REQUIRE((threads + 255) / 256 < 0x7fffffffL, PE_E_UNSUPPORTED, "%s: grid too large", what);
+        depthwise3x3_s1_kernel<<<(unsigned)((threads + 255) / 256), 256, 0, as_stream(stream)>>>(
+            static_cast<const uint16_t*>(x), B, H, W, C, dilation, static_cast<const uint16_t*>(w),
+            scale, shift, relu, static_cast<uint16_t*>(y), nty, ntx);
+        return check_launch(what);
+    }
     long blocks = (total + 255) / 256;
     if (blocks > 256 * 64) blocks = 256 * 64;
     depthwise3x3_kernel<<<(unsigned)blocks, 256, 0, as_stream(stream)>>>(
