@@ -45,10 +45,10 @@ __device__ __forceinline__ void unpack8(const uint4& v, float* f) {
 
 __device__ __forceinline__ uint4 pack8(const float* f) {
     uint4 o;
-    o.x = float_to_bf16_bits(f[0]) | (float_to_bf16_bits(f[1]) << 16);
-    o.y = float_to_bf16_bits(f[2]) | (float_to_bf16_bits(f[3]) << 16);
-    o.z = float_to_bf16_bits(f[4]) | (float_to_bf16_bits(f[5]) << 16);
-    o.w = float_to_bf16_bits(f[6]) | (float_to_bf16_bits(f[7]) << 16);
+    o.x = pack_bf16x2_bits(f[0], f[1]);
+    o.y = pack_bf16x2_bits(f[2], f[3]);
+    o.z = pack_bf16x2_bits(f[4], f[5]);
+    o.w = pack_bf16x2_bits(f[6], f[7]);
     return o;
 }
 

@@ -79,11 +79,17 @@ __device__ __forceinline__ float wave_sum(float x) {
 
 __device__ __forceinline__ float bf16_bits_to_float(uint32_t b) { return __uint_as_float(b << 16); }
 
-// Round-to-nearest-even float -> bf16 bits for finite inputs (NaN keeps a quiet-NaN pattern).
+// Two floats -> two bf16 (round to nearest even) packed lo | hi << 16: one v_cvt_pk_bf16_f32
+// on gfx950 instead of about a dozen integer instructions.
+__device__ __forceinline__ uint32_t pack_bf16x2_bits(float lo, float hi) {
+    typedef float pe_f32x2 __attribute__((ext_vector_type(2)));
+    typedef __bf16 pe_bf16x2 __attribute__((ext_vector_type(2)));
+    const pe_f32x2 v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, pe_bf16x2));
+}
+
 __device__ __forceinline__ uint32_t float_to_bf16_bits(float f) {
-    const uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;
-    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+    return pack_bf16x2_bits(f, 0.0f) & 0xffffu;
 }
 
 }  // namespace pe

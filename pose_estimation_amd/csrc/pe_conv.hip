@@ -102,10 +102,10 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const uint16_t* __res
         *reinterpret_cast<uint2*>(idx + ((b * Ho + oy) * Wo + ox) * (long)C + c8 * 8) = pk;
     }
     uint4 o;
-    o.x = float_to_bf16_bits(best[0]) | (float_to_bf16_bits(best[1]) << 16);
-    o.y = float_to_bf16_bits(best[2]) | (float_to_bf16_bits(best[3]) << 16);
-    o.z = float_to_bf16_bits(best[4]) | (float_to_bf16_bits(best[5]) << 16);
-    o.w = float_to_bf16_bits(best[6]) | (float_to_bf16_bits(best[7]) << 16);
+    o.x = pack_bf16x2_bits(best[0], best[1]);
+    o.y = pack_bf16x2_bits(best[2], best[3]);
+    o.z = pack_bf16x2_bits(best[4], best[5]);
+    o.w = pack_bf16x2_bits(best[6], best[7]);
     *reinterpret_cast<uint4*>(y + ((b * Ho + oy) * Wo + ox) * (long)C + c8 * 8) = o;
 }
 

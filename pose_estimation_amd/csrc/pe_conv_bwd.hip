@@ -118,10 +118,10 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_bwd_kernel(const uint8_t* __
             }
         }
         uint4 o;
-        o.x = float_to_bf16_bits(g[0]) | (float_to_bf16_bits(g[1]) << 16);
-        o.y = float_to_bf16_bits(g[2]) | (float_to_bf16_bits(g[3]) << 16);
-        o.z = float_to_bf16_bits(g[4]) | (float_to_bf16_bits(g[5]) << 16);
-        o.w = float_to_bf16_bits(g[6]) | (float_to_bf16_bits(g[7]) << 16);
+        o.x = pack_bf16x2_bits(g[0], g[1]);
+        o.y = pack_bf16x2_bits(g[2], g[3]);
+        o.z = pack_bf16x2_bits(g[4], g[5]);
+        o.w = pack_bf16x2_bits(g[6], g[7]);
         *reinterpret_cast<uint4*>(dx + e * 8) = o;
     }
 }

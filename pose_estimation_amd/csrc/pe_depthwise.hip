@@ -88,10 +88,10 @@ __global__ __launch_bounds__(256) void depthwise3x3_kernel(const uint16_t* __res
             }
         }
         uint4 o;
-        o.x = float_to_bf16_bits(acc[0]) | (float_to_bf16_bits(acc[1]) << 16);
-        o.y = float_to_bf16_bits(acc[2]) | (float_to_bf16_bits(acc[3]) << 16);
-        o.z = float_to_bf16_bits(acc[4]) | (float_to_bf16_bits(acc[5]) << 16);
-        o.w = float_to_bf16_bits(acc[6]) | (float_to_bf16_bits(acc[7]) << 16);
+        o.x = pack_bf16x2_bits(acc[0], acc[1]);
+        o.y = pack_bf16x2_bits(acc[2], acc[3]);
+        o.z = pack_bf16x2_bits(acc[4], acc[5]);
+        o.w = pack_bf16x2_bits(acc[6], acc[7]);
         *reinterpret_cast<uint4*>(y + e * 8) = o;
     }
 }
@@ -196,8 +196,8 @@ __global__ __launch_bounds__(256) void depthwise3x3_s1_kernel(const uint16_t* __
                 if (relu == 2) v[q] = fminf(v[q], 6.0f);
             }
             uint2 o;
-            o.x = float_to_bf16_bits(v[0]) | (float_to_bf16_bits(v[1]) << 16);
-            o.y = float_to_bf16_bits(v[2]) | (float_to_bf16_bits(v[3]) << 16);
+            o.x = pack_bf16x2_bits(v[0], v[1]);
+            o.y = pack_bf16x2_bits(v[2], v[3]);
             *reinterpret_cast<uint2*>(y + (((b * H + oy) * (long)W + ox) * C4 + c4) * 4) = o;
         }
     }

@@ -43,7 +43,7 @@ constexpr int ROWB = 128;  // bytes per LDS row (64 bf16, unpadded)
 __device__ __attribute__((aligned(16))) uint32_t g_zero16[4] = {0u, 0u, 0u, 0u};
 
 __device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {
-    return float_to_bf16_bits(a) | (float_to_bf16_bits(b) << 16);
+    return pack_bf16x2_bits(a, b);
 }
 
 // q = m / d, r = m % d for 0 <= m < 2^31, d >= 1 and quotients below 2^20: float reciprocal
@@ -269,15 +269,28 @@ __attribute__((amdgpu_waves_per_eu(MINB * WM / 2, MINB * WM / 2))) void igemm_ke
                 for (int a = 0; a < TN; ++a) {
                     const int col = a * 16 + nq;
                     const int n = n0 + half * HALF + col;
-                    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
-                    if (n < p.N) {
-                        if (p.scale) sc = *reinterpret_cast<const f32x4*>(p.scale + n);
-                        if (p.shift) sh = *reinterpret_cast<const f32x4*>(p.shift + n);
-                    }
+                    if (p.scale || p.shift) {  // uniform: training convs carry neither
+                        f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+                        if (n < p.N) {
+                            if (p.scale) sc = *reinterpret_cast<const f32x4*>(p.scale + n);
+                            if (p.shift) sh = *reinterpret_cast<const f32x4*>(p.shift + n);
+                        }
 #pragma unroll
-                    for (int b = 0; b < TM; ++b) {
-                        const int pr = wave_m * WROWS + b * 16 + lr;
-                        *reinterpret_cast<f32x4*>(cs + pr * CP + col) = acc[a][b] * sc + sh;
+                        for (int b = 0; b < TM; ++b) {
+                            const int pr = wave_m * WROWS + b * 16 + lr;
+                            f32x4 v;  // one fused multiply-add per element
+                            v.x = fmaf(acc[a][b].x, sc.x, sh.x);
+                            v.y = fmaf(acc[a][b].y, sc.y, sh.y);
+                            v.z = fmaf(acc[a][b].z, sc.z, sh.z);
+                            v.w = fmaf(acc[a][b].w, sc.w, sh.w);
+                            *reinterpret_cast<f32x4*>(cs + pr * CP + col) = v;
+                        }
+                    } else {
+#pragma unroll
+                        for (int b = 0; b < TM; ++b) {
+                            const int pr = wave_m * WROWS + b * 16 + lr;
+                            *reinterpret_cast<f32x4*>(cs + pr * CP + col) = acc[a][b];
+                        }
                     }
                 }
             }

@@ -48,8 +48,8 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
         v4[i] = vv;
         if (pb) {
             uint2 o;
-            o.x = float_to_bf16_bits(pp.x) | (float_to_bf16_bits(pp.y) << 16);
-            o.y = float_to_bf16_bits(pp.z) | (float_to_bf16_bits(pp.w) << 16);
+            o.x = pack_bf16x2_bits(pp.x, pp.y);
+            o.y = pack_bf16x2_bits(pp.z, pp.w);
             pb4[i] = o;
         }
     }
@@ -90,8 +90,8 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, float* 
         m4[i] = mm;
         if (pb) {
             uint2 o;
-            o.x = float_to_bf16_bits(pp.x) | (float_to_bf16_bits(pp.y) << 16);
-            o.y = float_to_bf16_bits(pp.z) | (float_to_bf16_bits(pp.w) << 16);
+            o.x = pack_bf16x2_bits(pp.x, pp.y);
+            o.y = pack_bf16x2_bits(pp.z, pp.w);
             pb4[i] = o;
         }
     }

@@ -156,10 +156,10 @@ __global__ __launch_bounds__(256) void vec_loss_kernel(VecLossArgs a) {
         if (HAS_GRAD) {
             u32x4 o;
             if constexpr (BF16) {
-                o.x = float_to_bf16_bits(gr[0]) | (float_to_bf16_bits(gr[1]) << 16);
-                o.y = float_to_bf16_bits(gr[2]) | (float_to_bf16_bits(gr[3]) << 16);
-                o.z = float_to_bf16_bits(gr[4]) | (float_to_bf16_bits(gr[5]) << 16);
-                o.w = float_to_bf16_bits(gr[6]) | (float_to_bf16_bits(gr[7]) << 16);
+                o.x = pack_bf16x2_bits(gr[0], gr[1]);
+                o.y = pack_bf16x2_bits(gr[2], gr[3]);
+                o.z = pack_bf16x2_bits(gr[4], gr[5]);
+                o.w = pack_bf16x2_bits(gr[6], gr[7]);
             } else {
                 o.x = __float_as_uint(gr[0]);
                 o.y = __float_as_uint(gr[1]);
