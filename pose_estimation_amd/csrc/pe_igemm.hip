@@ -51,13 +51,9 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {
 __device__ __forceinline__ void fast_divmod(int m, int d, float inv_d, int& q, int& r) {
     q = (int)((float)m * inv_d);
     r = m - q * d;
-    if (r < 0) {
-        --q;
-        r += d;
-    } else if (r >= d) {
-        ++q;
-        r -= d;
-    }
+    const int fix = (r >= d ? 1 : 0) - (r < 0 ? 1 : 0);
+    q += fix;
+    r -= fix * d;
 }
 
 template <int BM, int BN, int WM, bool DB, bool PF, int MINB>

@@ -42,13 +42,9 @@ __device__ __attribute__((aligned(16))) uint32_t g_wzero16[4] = {0u, 0u, 0u, 0u}
 __device__ __forceinline__ void fast_divmod(int m, int d, float inv_d, int& q, int& r) {
     q = (int)((float)m * inv_d);
     r = m - q * d;
-    if (r < 0) {
-        --q;
-        r += d;
-    } else if (r >= d) {
-        ++q;
-        r -= d;
-    }
+    const int fix = (r >= d ? 1 : 0) - (r < 0 ? 1 : 0);  // branch-free: this runs every K step
+    q += fix;
+    r -= fix * d;
 }
 
 __device__ __forceinline__ bf16x8 tr_frag(const char* tile, int off_lo) {
@@ -59,6 +55,9 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* tile, int off_lo) {
     return __builtin_bit_cast(bf16x8, v);
 }
 
+// FLAT: a 1x1 stride-1 conv with an identity output grid, where input pixel = output pixel =
+// GEMM row and the per-step index split disappears (two thirds of the network's layers).
+template <bool FLAT>
 __global__ __launch_bounds__(256, 4) void wgrad_kernel(const WgradParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* ytile = smem;
@@ -130,20 +129,24 @@ __global__ __launch_bounds__(256, 4) void wgrad_kernel(const WgradParams p) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const long m = mb + rr + 16 * i;
-            const uint16_t* ysrc = zero;
-            const uint16_t* xsrc = zero;
-            if (m < me) {
+            const bool mv = m < me;
+            const uint16_t* ysrc;
+            const uint16_t* xsrc;
+            if constexpr (FLAT) {
+                ysrc = (mv && n_ok) ? p.dy + m * p.ldy + nn : zero;
+                xsrc = (mv && c_ok) ? p.x + m * p.Cx + xch : zero;
+            } else {
                 int b, rem, oy, ox;
                 fast_divmod((int)m, HoWo, inv_howo, b, rem);
                 fast_divmod(rem, p.Wo, inv_wo, oy, ox);
-                if (n_ok) {
-                    const long opix = (long)b * OHW + (oy * p.osy + p.ooy) * p.OW + ox * p.osx + p.oox;
-                    ysrc = p.dy + opix * p.ldy + nn;
-                }
+                const long opix = (long)b * OHW + (oy * p.osy + p.ooy) * p.OW + ox * p.osx + p.oox;
+                ysrc = (mv && n_ok) ? p.dy + opix * p.ldy + nn : zero;
                 const int iy = oy * p.sy + tdy;
                 const int ix = ox * p.sx + tdx;
-                if (c_ok && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi)
-                    xsrc = p.x + (((long)b * p.Hi * p.Wi + (long)iy * p.Wi + ix) * p.Cx + xch);
+                const bool inb = (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+                xsrc = (mv && c_ok && inb)
+                           ? p.x + (((long)b * p.Hi * p.Wi + (long)iy * p.Wi + ix) * p.Cx + xch)
+                           : zero;
             }
             __builtin_amdgcn_global_load_lds((gptr_t)ysrc,
                                              (lptr_t)(ytile + (16 * i + 4 * wid) * WG_ROWB), 16, 0, 0);
@@ -281,7 +284,13 @@ int32_t wgrad_launch(WgradParams& p, void* workspace, size_t workspace_bytes, hi
                    (size_t)splits * (size_t)P * sizeof(float));
     }
     const size_t lds = 64 * 132 * sizeof(float);  // epilogue half tile (33.8 KB) > K tiles (32 KB)
-    wgrad_kernel<<<dim3((unsigned)tiles, (unsigned)splits), 256, lds, st>>>(p);
+    const bool flat = p.T == 1 && p.tap_dy[0] == 0 && p.tap_dx[0] == 0 && p.sy == 1 && p.sx == 1 &&
+                      p.Hi == p.Ho && p.Wi == p.Wo && p.OH == p.Ho && p.OW == p.Wo && p.osy == 1 &&
+                      p.osx == 1 && p.ooy == 0 && p.oox == 0 && p.cshift == 31;
+    if (flat)
+        wgrad_kernel<true><<<dim3((unsigned)tiles, (unsigned)splits), 256, lds, st>>>(p);
+    else
+        wgrad_kernel<false><<<dim3((unsigned)tiles, (unsigned)splits), 256, lds, st>>>(p);
     int32_t rc = check_launch(what);
     if (rc != PE_OK || splits == 1) return rc;
     const long groups = P >> 2;
