@@ -220,6 +220,46 @@ class VecLoss(VecRender):
                 "sample": "NumPy oracle, 16-image batch, one run"}
 
 
+class Augment(Workload):
+    """Input pipeline: 640x480 uint8 frames -> scale jitter / crop / flip / normalise -> the
+    320x320 bf16 space-to-depth image, plus the joint transform (the reference's configured
+    augmentation, test.ipynb:995-1010)."""
+    name = "augment_640x480_to_320x320_b256"
+    batch = 256
+    dtype = "f32"
+    kernel = "augment_s2d_kernel"
+    # reads the 640x480x3 frame at most once, writes 320x320 pixels x 8 bytes (16 bf16 per 2x2)
+    bytes_per_step = batch * (480 * 640 * 3 + 320 * 320 * 8)
+
+    def setup(self, device):
+        from pose_estimation_amd import augment
+
+        self.aug = augment
+        self.imgs = [torch.from_numpy(synthetic.images_u8(self.batch, 480, 640, seed=1 + i)).to(device)
+                     for i in range(3)]
+        self.prm = torch.from_numpy(augment.random_params(self.batch, (480, 640), (320, 320),
+                                                          seed=3)).to(device)
+        self.j = torch.from_numpy(synthetic.joints(self.batch, K_JOINTS, 480, 640)).to(device)
+        self.out = torch.empty(self.batch, 160, 160, 16, dtype=torch.bfloat16, device=device)
+
+    def step(self, i):
+        self.aug.augment_u8(self.imgs[i % 3], self.prm, (320, 320), out=self.out)
+        self.aug.transform_joints(self.j, self.prm, 320, self.aug.COCO_FLIP_PERM)
+
+    def cpu_baseline(self):
+        import oracle
+        from pose_estimation_amd import augment
+        from pose_estimation_amd import nn as pnn
+
+        img = synthetic.images_u8(8, 480, 640, seed=1)
+        prm = augment.random_params(8, (480, 640), (320, 320), seed=3)
+        t0 = time.perf_counter()
+        oracle.augment_u8(img, prm, (320, 320), pnn.IMAGENET_MEAN, pnn.IMAGENET_STD)
+        dt = time.perf_counter() - t0
+        return {"value": 8 / dt, "unit": "images/s", "cores": 1, "kind": "port",
+                "sample": "NumPy oracle, 8-image batch, one run"}
+
+
 class Adam(Workload):
     name = "adam_34M_f32"
     batch = 1  # one optimizer step
@@ -413,6 +453,7 @@ class Train(Workload):
 
 WORKLOADS = {"decode": Decode, "render": Render, "mse": Mse, "mse_fused": MseFused, "adam": Adam,
              "vecmap": VecRender, "vecmap_loss": VecLoss, "mobilenet": MobileNetInfer,
+             "augment": Augment,
              "infer": Infer, "train": Train}
 
 

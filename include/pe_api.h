@@ -253,6 +253,29 @@ int32_t pe_preprocess_u8_s2d_bf16(const uint8_t* img, int32_t B, int32_t H, int3
                                   const float* mean3, const float* std3, void* x_s2d,
                                   pe_stream_t stream);
 
+/* Input pipeline in front of the stem.  Replaces the resize / augmentation / normalisation of
+ * the reference's tf.data map function (dataset/pose_data.py, PoseEstimation.pyproj:27; absent;
+ * configuration printed at test.ipynb:995-1010: flip_left_right, random_crop, scale_range
+ * [0.5, 2.0], image_resize [320, 320]).
+ * img [B,Hs,Ws,3] uint8; params_device: DEVICE float32 [B][5] = (sx, sy, tx, ty, flip) with
+ *   u = (xf + 0.5)*sx + tx - 0.5,  v = (y + 0.5)*sy + ty - 0.5,  xf = flip ? W-1-x : x
+ * the source coordinates of output pixel (x, y), sampled bilinearly (outside the frame = 0),
+ * then (value/255 - mean[c]) / std[c] (HOST arrays), written as the bf16 space-to-depth image
+ * x_s2d [B,H/2,W/2,16] the stem entries read.  A plain resize is sx = Ws/W, sy = Hs/H, t = 0.
+ * pe_transform_joints_f32 applies the inverse map to joints [B,K,3] (x, y, v):
+ *   xo = (x + 0.5 - tx)/sx - 0.5 (mirrored to W-1-xo when flipped), likewise y; when flipped,
+ *   output joint k is read from input joint flip_perm_host[k] (HOST array of K indices, NULL =
+ *   identity), which exchanges left and right joints.  joints_out must not alias joints_in. */
+int32_t pe_augment_u8_s2d_bf16(const uint8_t* img, int32_t B, int32_t Hs, int32_t Ws,
+                               const float* params_device, int32_t H, int32_t W,
+                               const float* mean3, const float* std3, void* x_s2d,
+                               pe_stream_t stream);
+
+int32_t pe_transform_joints_f32(const float* joints_in, int32_t B, int32_t K,
+                                const float* params_device, int32_t W,
+                                const int32_t* flip_perm_host, float* joints_out,
+                                pe_stream_t stream);
+
 /* 3x3 stride-2 pad-1 max pool, NHWC bf16: [B,H,W,C] -> [B,H/2,W/2,C] (H, W even; C % 8 == 0).
  * idx (may be NULL; training passes it): uint8 [B,H/2,W/2,C], the window position ky*3+kx of
  * each output's first maximum in row-major scan order. */

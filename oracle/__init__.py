@@ -20,6 +20,8 @@ from .numpy_oracle import (  # noqa: F401
     gaussian_table,
     render_targets,
     render_vecmaps,
+    augment_u8,
+    transform_joints,
     vecmap_loss_fwd_bwd,
     mse_fwd_bwd,
     adam_step,

@@ -152,6 +152,71 @@ def render_targets(joints, H: int, W: int, stride: float, sigma: float, radius: 
 
 
 # --------------------------------------------------------------------------
+# input pipeline: affine resample (resize / scale / crop / flip) + normalise
+# --------------------------------------------------------------------------
+def augment_u8(img_u8, params, out_hw, mean, std):
+    """uint8 [B,Hs,Ws,3], params [B,5] = (sx, sy, tx, ty, flip) -> float32 [B,H,W,3] holding
+    bf16-representable values (the kernel writes the same values in space-to-depth order).
+
+    Output pixel (x, y) reads source (u, v) = ((xf+.5)*sx + tx - .5, (y+.5)*sy + ty - .5) with
+    xf = W-1-x when flipped, bilinear: top = p00 + fx*(p01-p00), bot likewise, val = top +
+    fy*(bot-top); taps outside the frame are 0; then (val/255 - mean) * (1/std).  Every step is
+    one float32 operation in this order.  Follows the configuration the reference prints
+    (test.ipynb:995-1010); its own resampling code (dataset/pose_data.py) is absent.
+    """
+    img = np.asarray(img_u8)
+    B, Hs, Ws, _ = img.shape
+    H, W = out_hw
+    prm = np.asarray(params, dtype=F32)
+    m = np.asarray(mean, F32)
+    inv = (F32(1.0) / np.asarray(std, F32)).astype(F32)
+    out = np.zeros((B, H, W, 3), F32)
+    ys = np.arange(H, dtype=F32)
+    xs = np.arange(W, dtype=F32)
+    for b in range(B):
+        sx, sy, tx, ty, flip = (F32(v) for v in prm[b])
+        xf = (F32(W - 1) - xs) if flip != 0 else xs
+        u = (((xf + F32(0.5)) * sx).astype(F32) + tx).astype(F32) - F32(0.5)
+        v = (((ys + F32(0.5)) * sy).astype(F32) + ty).astype(F32) - F32(0.5)
+        uf, vf = np.floor(u), np.floor(v)
+        fx = (u - uf).astype(F32)[None, :, None]
+        fy = (v - vf).astype(F32)[:, None, None]
+        x0 = np.clip(uf, -1e9, 1e9).astype(np.int64)
+        y0 = np.clip(vf, -1e9, 1e9).astype(np.int64)
+
+        def tap(yy, xx):
+            ok = ((yy >= 0) & (yy < Hs))[:, None] & ((xx >= 0) & (xx < Ws))[None, :]
+            g = img[b][np.clip(yy, 0, Hs - 1)[:, None], np.clip(xx, 0, Ws - 1)[None, :]].astype(F32)
+            return np.where(ok[..., None], g, F32(0))
+
+        p00, p01 = tap(y0, x0), tap(y0, x0 + 1)
+        p10, p11 = tap(y0 + 1, x0), tap(y0 + 1, x0 + 1)
+        top = (p00 + (fx * (p01 - p00)).astype(F32)).astype(F32)
+        bot = (p10 + (fx * (p11 - p10)).astype(F32)).astype(F32)
+        val = (top + (fy * (bot - top)).astype(F32)).astype(F32)
+        out[b] = (((val / F32(255.0)).astype(F32) - m).astype(F32) * inv).astype(F32)
+    return bf16_round(out)
+
+
+def transform_joints(joints, params, out_w: int, flip_perm=None):
+    """Inverse of augment_u8's map for joints [B,K,3]: xo = (x + .5 - tx)/sx - .5 (W-1-xo when
+    flipped), yo likewise; when flipped, output joint k is source joint flip_perm[k]."""
+    j = np.asarray(joints, dtype=F32)
+    prm = np.asarray(params, dtype=F32)
+    B, K, _ = j.shape
+    out = np.empty_like(j)
+    for b in range(B):
+        sx, sy, tx, ty, flip = (F32(v) for v in prm[b])
+        src = j[b][list(flip_perm)] if (flip != 0 and flip_perm is not None) else j[b]
+        xo = (((src[:, 0] + F32(0.5)) - tx).astype(F32) / sx).astype(F32) - F32(0.5)
+        yo = (((src[:, 1] + F32(0.5)) - ty).astype(F32) / sy).astype(F32) - F32(0.5)
+        if flip != 0:
+            xo = (F32(out_w - 1) - xo).astype(F32)
+        out[b, :, 0], out[b, :, 1], out[b, :, 2] = xo, yo, src[:, 2]
+    return out
+
+
+# --------------------------------------------------------------------------
 # vector maps: per keypoint pair, the integer cell offset to the partner joint
 # --------------------------------------------------------------------------
 VEC_MAX_CENTRE = 1 << 20  # centres further out than this are treated as unlabelled

@@ -100,6 +100,14 @@ SIGNATURES = {
         c_int32,
         [c_void_p, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p],
     ),
+    "pe_augment_u8_s2d_bf16": (
+        c_int32,
+        [c_void_p, c_int32, c_int32, c_int32, c_void_p, c_int32, c_int32, c_void_p, c_void_p,
+         c_void_p, c_void_p],
+    ),
+    "pe_transform_joints_f32": (
+        c_int32, [c_void_p, c_int32, c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_void_p],
+    ),
     "pe_maxpool3x3s2_fwd_bf16": (
         c_int32, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p],
     ),

@@ -1,0 +1,169 @@
+// GPU-side input pipeline in front of the stem: resize + scale jitter + crop + left-right flip +
+// normalisation of uint8 frames, written straight into the bf16 space-to-depth image the stem
+// kernels read, and the matching transform of the joint coordinates.
+//
+// The reference does this in its tf.data map function (dataset/pose_data.py,
+// PoseEstimation.pyproj:27; absent); its configuration is printed at test.ipynb:995-1010:
+// augmentation {flip_left_right, random_crop, scale_range [0.5, 2.0]}, preprocess
+// {image_resize [320, 320]}.  Here one affine map per image carries all of it:
+//     u = (xf + 0.5) * sx + tx - 0.5,   v = (y + 0.5) * sy + ty - 0.5,   xf = flip ? W-1-x : x
+// maps output pixel (x, y) to source coordinates, sampled bilinearly (outside the frame = 0),
+// then (value / 255 - mean) / std.  All arithmetic is float32 in a fixed order, so the result
+// is bit-identical to the CPU restatement.
+//
+// Bound: HBM bandwidth (reads at most 4 x 3 bytes per output pixel from cache-friendly rows,
+// writes 8 bytes per pixel).  One thread per 2x2 output block = one space-to-depth pixel.
+#include <math.h>
+
+#include "pe_common.h"
+
+namespace pe {
+
+struct AugNorm {
+    float mean[3];
+    float inv_std[3];
+};
+
+__device__ __forceinline__ float aug_tap(const uint8_t* __restrict__ img, int Hs, int Ws, int yy,
+                                         int xx, int c) {
+    const bool ok = (unsigned)yy < (unsigned)Hs && (unsigned)xx < (unsigned)Ws;
+    const long off = ok ? ((long)yy * Ws + xx) * 3 + c : 0;
+    const float v = (float)img[off];
+    return ok ? v : 0.0f;
+}
+
+__global__ __launch_bounds__(256) void augment_s2d_kernel(const uint8_t* __restrict__ img, int B,
+                                                          int Hs, int Ws,
+                                                          const float* __restrict__ params, int H2,
+                                                          int W2, AugNorm nm,
+                                                          uint4* __restrict__ out) {
+    const long npix2 = (long)B * H2 * W2;
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= npix2) return;
+    const int X = (int)(t % W2);
+    const long r = t / W2;
+    const int Y = (int)(r % H2);
+    const long b = r / H2;
+    const int W = 2 * W2;
+    const float sx = params[b * 5 + 0], sy = params[b * 5 + 1];
+    const float tx = params[b * 5 + 2], ty = params[b * 5 + 3];
+    const bool flip = params[b * 5 + 4] != 0.0f;
+    const uint8_t* src = img + b * (long)Hs * Ws * 3;
+    float h[12];
+#pragma unroll
+    for (int ry = 0; ry < 2; ++ry) {
+        const int y = 2 * Y + ry;
+        const float v = ((float)y + 0.5f) * sy + ty - 0.5f;
+        const float vf = floorf(v);
+        const float fy = v - vf;
+        const int y0 = (int)fminf(fmaxf(vf, -1.0e9f), 1.0e9f);
+#pragma unroll
+        for (int rx = 0; rx < 2; ++rx) {
+            const int x = 2 * X + rx;
+            const int xf = flip ? W - 1 - x : x;
+            const float u = ((float)xf + 0.5f) * sx + tx - 0.5f;
+            const float uf = floorf(u);
+            const float fx = u - uf;
+            const int x0 = (int)fminf(fmaxf(uf, -1.0e9f), 1.0e9f);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float p00 = aug_tap(src, Hs, Ws, y0, x0, c);
+                const float p01 = aug_tap(src, Hs, Ws, y0, x0 + 1, c);
+                const float p10 = aug_tap(src, Hs, Ws, y0 + 1, x0, c);
+                const float p11 = aug_tap(src, Hs, Ws, y0 + 1, x0 + 1, c);
+                const float top = p00 + fx * (p01 - p00);
+                const float bot = p10 + fx * (p11 - p10);
+                const float val = top + fy * (bot - top);
+                h[(ry * 2 + rx) * 3 + c] = (val / 255.0f - nm.mean[c]) * nm.inv_std[c];
+            }
+        }
+    }
+    uint4 lo, hi;
+    lo.x = pack_bf16x2_bits(h[0], h[1]);
+    lo.y = pack_bf16x2_bits(h[2], h[3]);
+    lo.z = pack_bf16x2_bits(h[4], h[5]);
+    lo.w = pack_bf16x2_bits(h[6], h[7]);
+    hi.x = pack_bf16x2_bits(h[8], h[9]);
+    hi.y = pack_bf16x2_bits(h[10], h[11]);
+    hi.z = 0u;
+    hi.w = 0u;
+    out[2 * t] = lo;
+    out[2 * t + 1] = hi;
+}
+
+struct JointPerm {
+    int16_t to[64];
+};
+
+// Inverse of the image map for coordinates: xo = (x + 0.5 - tx) / sx - 0.5, mirrored when the
+// image was flipped, and with left/right joints exchanged through `perm` in that case.
+__global__ __launch_bounds__(256) void transform_joints_kernel(const float* __restrict__ jin, int B,
+                                                               int K, const float* __restrict__ params,
+                                                               int W, JointPerm perm,
+                                                               float* __restrict__ jout) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= B * K) return;
+    const int b = t / K, k = t - b * K;
+    const float sx = params[b * 5 + 0], sy = params[b * 5 + 1];
+    const float tx = params[b * 5 + 2], ty = params[b * 5 + 3];
+    const bool flip = params[b * 5 + 4] != 0.0f;
+    const int ks = flip ? perm.to[k] : k;   // output joint k takes source joint ks
+    const float* s = jin + ((long)b * K + ks) * 3;
+    float xo = (s[0] + 0.5f - tx) / sx - 0.5f;
+    const float yo = (s[1] + 0.5f - ty) / sy - 0.5f;
+    if (flip) xo = (float)(W - 1) - xo;
+    float* d = jout + ((long)b * K + k) * 3;
+    d[0] = xo;
+    d[1] = yo;
+    d[2] = s[2];
+}
+
+}  // namespace pe
+
+using namespace pe;
+
+extern "C" int32_t pe_augment_u8_s2d_bf16(const uint8_t* img, int32_t B, int32_t Hs, int32_t Ws,
+                                          const float* params_device, int32_t H, int32_t W,
+                                          const float* mean3, const float* std3, void* x_s2d,
+                                          pe_stream_t stream) {
+    const char* what = "pe_augment_u8_s2d_bf16";
+    PE_REQUIRE(img && params_device && mean3 && std3 && x_s2d, PE_E_INVALID, "%s: NULL pointer", what);
+    PE_REQUIRE(B > 0 && Hs > 0 && Ws > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0,
+               PE_E_INVALID, "%s: sizes must be positive and the output size even", what);
+    PE_REQUIRE(aligned(x_s2d, 16), PE_E_INVALID, "%s: output misaligned", what);
+    const long npix2 = (long)B * (H / 2) * (W / 2);
+    PE_REQUIRE(npix2 < 0x7fffffffL && (long)Hs * Ws * 3 < 0x7fffffffL, PE_E_UNSUPPORTED,
+               "%s: too many pixels", what);
+    AugNorm nm;
+    for (int c = 0; c < 3; ++c) {
+        PE_REQUIRE(std3[c] > 0.0f, PE_E_INVALID, "%s: std must be positive", what);
+        nm.mean[c] = mean3[c];
+        nm.inv_std[c] = 1.0f / std3[c];
+    }
+    augment_s2d_kernel<<<(unsigned)((npix2 + 255) / 256), 256, 0, as_stream(stream)>>>(
+        img, B, Hs, Ws, params_device, H / 2, W / 2, nm, static_cast<uint4*>(x_s2d));
+    return check_launch(what);
+}
+
+extern "C" int32_t pe_transform_joints_f32(const float* joints_in, int32_t B, int32_t K,
+                                           const float* params_device, int32_t W,
+                                           const int32_t* flip_perm_host, float* joints_out,
+                                           pe_stream_t stream) {
+    const char* what = "pe_transform_joints_f32";
+    PE_REQUIRE(joints_in && params_device && joints_out, PE_E_INVALID, "%s: NULL pointer", what);
+    PE_REQUIRE(B > 0 && K > 0 && K <= 64 && W > 0, PE_E_UNSUPPORTED,
+               "%s: need B > 0, 0 < K <= 64, W > 0", what);
+    PE_REQUIRE(joints_in != joints_out, PE_E_INVALID, "%s: in-place transform is not supported", what);
+    JointPerm perm;
+    for (int k = 0; k < 64; ++k) perm.to[k] = (int16_t)k;
+    if (flip_perm_host) {
+        for (int k = 0; k < K; ++k) {
+            PE_REQUIRE(flip_perm_host[k] >= 0 && flip_perm_host[k] < K, PE_E_INVALID,
+                       "%s: flip_perm[%d] = %d out of range", what, k, flip_perm_host[k]);
+            perm.to[k] = (int16_t)flip_perm_host[k];
+        }
+    }
+    transform_joints_kernel<<<(unsigned)((B * K + 255) / 256), 256, 0, as_stream(stream)>>>(
+        joints_in, B, K, params_device, W, perm, joints_out);
+    return check_launch(what);
+}
