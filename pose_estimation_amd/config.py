@@ -39,6 +39,9 @@ DEFAULTS: Dict[str, Dict[str, Any]] = {
         "optimizer": {"name": "adam",
                       "params": {"beta1": 0.9, "beta2": 0.999, "epsilon": "1e-8"}},
         "preprocess": {"image_resize": [256, 192]},
+        # the reference trains with {"flip_left_right": True, "random_crop": True,
+        # "scale_range": [0.5, 2.0]} (test.ipynb:995-997); None = frames are fed as they are
+        "augmentation": None,
         "model_dir": "./models",
         "num_epochs": 0,
         "train_keypoints": None,

@@ -14,7 +14,7 @@ from typing import Dict, Iterator, Optional, Tuple
 import numpy as np
 import torch
 
-from . import ops, synthetic
+from . import augment, ops, synthetic
 from .config import learning_rate_at, parse_config
 from .model import init_state
 from .training import TrainablePoseResNet
@@ -88,6 +88,30 @@ class Trainer:
         else:
             images, joints = features, labels
         t = self.train_cfg
+        x_s2d = None
+        H, W = t.preprocess["image_resize"]
+        aug_cfg = getattr(t, "augmentation", None)
+        if aug_cfg or tuple(images.shape[1:3]) != (H, W):
+            # frames of any size: resize (+ the configured augmentation) on the GPU, straight
+            # into the stem's input layout; joints follow the same map
+            if mask is not None:
+                raise ValueError("an ignore mask cannot follow the resize/augmentation map; "
+                                 "pass frames at image_resize without augmentation, or no mask")
+            B = images.shape[0]
+            src_hw = (int(images.shape[1]), int(images.shape[2]))
+            if aug_cfg:
+                prm = augment.random_params(
+                    B, src_hw, (H, W), tuple(aug_cfg.get("scale_range", (1.0, 1.0))),
+                    bool(aug_cfg.get("flip_left_right", False)),
+                    bool(aug_cfg.get("random_crop", False)),
+                    seed=int(self.data_cfg.seed) + 7919 * self.global_step)
+            else:
+                prm = augment.resize_params(B, src_hw, (H, W))
+            prm_t = torch.from_numpy(prm).to(images.device)
+            x_s2d = augment.augment_u8(images, prm_t, (H, W))
+            perm = augment.COCO_FLIP_PERM if joints.shape[1] == 17 else None
+            joints = augment.transform_joints(joints, prm_t, W, perm)
+            images = None
         lr = learning_rate_at(t, self.global_step)
         opt = t.optimizer
         params = opt.get("params", {})
@@ -96,10 +120,10 @@ class Trainer:
             loss, _ = net.train_step(images, joints, mask, lr=lr, optimizer="adam",
                                      beta1=float(params.get("beta1", 0.9)),
                                      beta2=float(params.get("beta2", 0.999)),
-                                     eps=float(params.get("epsilon", 1e-8)))
+                                     eps=float(params.get("epsilon", 1e-8)), x_s2d=x_s2d)
         elif name in ("sgd", "momentum"):
             loss, _ = net.train_step(images, joints, mask, lr=lr, optimizer="sgd",
-                                     momentum=float(params.get("momentum", 0.9)))
+                                     momentum=float(params.get("momentum", 0.9)), x_s2d=x_s2d)
         else:
             raise ValueError(f"unknown optimizer {name!r}")
         self.global_step += 1

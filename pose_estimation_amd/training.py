@@ -166,10 +166,13 @@ class TrainablePoseResNet(PoseResNet):
         self._done(d)
         return pnn.deconv4x4s2_bwd_data(dz, self.wt[d.name])
 
-    def forward_train(self, images_u8: torch.Tensor) -> torch.Tensor:
+    def forward_train(self, images_u8: Optional[torch.Tensor],
+                      x_s2d: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Forward with batch statistics.  Give uint8 images at network resolution, or x_s2d, the
+        normalised space-to-depth image an input pipeline (augment.augment_u8) already made."""
         stem, blocks, deconvs, final = self.specs
         sv: dict = {"blocks": [], "deconvs": []}
-        xs = pnn.preprocess_u8(images_u8)
+        xs = x_s2d if x_s2d is not None else pnn.preprocess_u8(images_u8)
         z0 = pnn.stem7x7s2(xs, self.w(stem), None, None, relu=False)
         a0 = self._bn(stem, z0)
         x, pool_idx = pnn.maxpool3x3s2(a0, want_index=True)
@@ -228,10 +231,11 @@ class TrainablePoseResNet(PoseResNet):
     def train_step(self, images_u8: torch.Tensor, joints: torch.Tensor,
                    mask: Optional[torch.Tensor] = None, lr: float = 1e-3, optimizer: str = "adam",
                    beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8,
-                   momentum: float = 0.9):
-        """images uint8 [B,H,W,3]; joints float32 [B,K,3] (x, y, v) in input pixels; mask
-        uint8 [B,H/4,W/4] or None.  Returns (loss [1] float32 device tensor, per_joint [K])."""
-        hm = self.forward_train(images_u8)
+                   momentum: float = 0.9, x_s2d: Optional[torch.Tensor] = None):
+        """images uint8 [B,H,W,3] (or None with x_s2d given, see forward_train); joints float32
+        [B,K,3] (x, y, v) in input pixels; mask uint8 [B,H/4,W/4] or None.
+        Returns (loss [1] float32 device tensor, per_joint [K])."""
+        hm = self.forward_train(images_u8, x_s2d)
         loss, per_joint, grad, _ = ops.mse_fwd_bwd(hm, joints=joints, mask=mask,
                                                   stride=self.heatmap_stride, sigma=self.sigma,
                                                   radius=self.radius)
