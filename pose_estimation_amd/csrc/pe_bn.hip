@@ -71,29 +71,49 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const uint16_t* __restri
     float s1[8], s2[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) s1[i] = s2[i] = 0.0f;
-    for (long r = row0 + rli; r < row1; r += g.rl) {
-        const long off = r * C + cgi * 8;
-        float zf[8];
-        unpack8(*reinterpret_cast<const uint4*>(z + off), zf);
-        if (MODE == 0) {
+    // a workgroup walks its rows U at a time: with at most 1024 workgroups on 256 CUs, one
+    // 16-byte load per thread in flight is half of what HBM needs; U loads are issued together
+    // (rows past the end re-read the last row and are masked out of the sums)
+    constexpr int U = MODE == 0 ? 4 : 2;
+    for (long r = row0 + rli; r < row1; r += (long)U * g.rl) {
+        uint4 zv[U], gv[U], av[U];
+        bool live[U];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                s1[i] += zf[i];
-                s2[i] += zf[i] * zf[i];
+        for (int u = 0; u < U; ++u) {
+            const long rr = r + (long)u * g.rl;
+            live[u] = rr < row1;
+            const long off = (live[u] ? rr : r) * C + cgi * 8;
+            zv[u] = *reinterpret_cast<const uint4*>(z + off);
+            if (MODE == 1) {
+                gv[u] = *reinterpret_cast<const uint4*>(da + off);
+                if (a) av[u] = *reinterpret_cast<const uint4*>(a + off);
             }
-        } else {
-            float gf[8];
-            unpack8(*reinterpret_cast<const uint4*>(da + off), gf);
-            if (a) {
-                float af[8];
-                unpack8(*reinterpret_cast<const uint4*>(a + off), af);
+        }
 #pragma unroll
-                for (int i = 0; i < 8; ++i) gf[i] = af[i] > 0.0f ? gf[i] : 0.0f;
-            }
+        for (int u = 0; u < U; ++u) {
+            if (!live[u]) continue;
+            float zf[8];
+            unpack8(zv[u], zf);
+            if (MODE == 0) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                s1[i] += gf[i];
-                s2[i] += gf[i] * zf[i];
+                for (int i = 0; i < 8; ++i) {
+                    s1[i] += zf[i];
+                    s2[i] += zf[i] * zf[i];
+                }
+            } else {
+                float gf[8];
+                unpack8(gv[u], gf);
+                if (a) {
+                    float af[8];
+                    unpack8(av[u], af);
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) gf[i] = af[i] > 0.0f ? gf[i] : 0.0f;
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    s1[i] += gf[i];
+                    s2[i] += gf[i] * zf[i];
+                }
             }
         }
     }
