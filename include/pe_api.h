@@ -371,6 +371,30 @@ int32_t pe_bn_bwd_bf16(const void* da, const void* a, const void* z, int64_t M, 
                        float* dbeta, void* dz, void* dmasked, void* workspace,
                        pe_stream_t stream);
 
+/* Forward convolutions that also leave the batch-norm statistics of their own output behind,
+ * so the training forward pass does not read z again to reduce it.  Same operands as
+ * pe_conv2d_fwd_bf16 / pe_deconv4x4s2_fwd_bf16 / pe_stem7x7s2_fwd_bf16 with no epilogue
+ * (no scale, shift, residual or ReLU; bf16 NHWC output; Cout % 8 == 0).  Each GEMM tile writes
+ * one partial row {sum z, sum z*z}[Cout] (of the bf16-rounded z it stored) into bn_workspace,
+ * sized by pe_bn_workspace_bytes(M, Cout); *rows_out (host memory, written before the call
+ * returns) receives the number of rows.  pe_bn_finalize_bf16 folds them in a fixed order and
+ * does what the second half of pe_bn_stats_bf16 does.  Same layers replaced as above. */
+int32_t pe_conv2d_fwd_bnstats_bf16(const pe_conv_desc* d, const void* x, const void* w, void* y,
+                                   void* bn_workspace, size_t workspace_bytes, int32_t* rows_out,
+                                   pe_stream_t stream);
+int32_t pe_deconv4x4s2_fwd_bnstats_bf16(int32_t B, int32_t H, int32_t W, int32_t Cin,
+                                        int32_t Cout, const void* x, const void* w_phases,
+                                        void* y, void* bn_workspace, size_t workspace_bytes,
+                                        int32_t* rows_out, pe_stream_t stream);
+int32_t pe_stem7x7s2_fwd_bnstats_bf16(int32_t B, int32_t H2, int32_t W2, int32_t Cout,
+                                      const void* x_s2d, const void* w, void* y,
+                                      void* bn_workspace, size_t workspace_bytes,
+                                      int32_t* rows_out, pe_stream_t stream);
+int32_t pe_bn_finalize_bf16(const void* workspace, int32_t rows, int64_t M, int32_t C,
+                            const float* gamma, const float* beta, float eps, float momentum,
+                            float* running_mean, float* running_var, float* mean, float* rstd,
+                            float* scale, float* shift, pe_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -145,6 +145,17 @@ SIGNATURES = {
     ),
     "pe_mul_f32": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p]),
     "pe_bn_workspace_bytes": (c_size_t, [c_int64, c_int32]),
+    "pe_conv2d_fwd_bnstats_bf16": (
+        c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
+    "pe_deconv4x4s2_fwd_bnstats_bf16": (
+        c_int32, [c_int32] * 5 + [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p,
+                                  c_void_p]),
+    "pe_stem7x7s2_fwd_bnstats_bf16": (
+        c_int32, [c_int32] * 4 + [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p,
+                                  c_void_p]),
+    "pe_bn_finalize_bf16": (
+        c_int32, [c_void_p, c_int32, c_int64, c_int32, c_void_p, c_void_p, c_float, c_float]
+        + [c_void_p] * 7),
     "pe_bn_stats_bf16": (
         c_int32,
         [c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_float, c_float, c_void_p, c_void_p,

@@ -288,8 +288,30 @@ using namespace pe;
 
 extern "C" size_t pe_bn_workspace_bytes(int64_t M, int32_t C) {
     if (M <= 0 || C <= 0 || C % 8 != 0 || C > 2048 || 256 % (C / 8) != 0) return 16;
-    // per-block partials + three per-channel coefficient rows for the backward pass
-    return ((size_t)kBnMaxBlocks * 2 + 3) * (size_t)C * sizeof(float);
+    // per-block partials (or one row per 64-pixel conv tile when the statistics come from the
+    // conv epilogue) + three per-channel coefficient rows for the backward pass
+    size_t rows = (size_t)(M / 64) + 8;
+    if (rows < (size_t)kBnMaxBlocks) rows = kBnMaxBlocks;
+    return (rows * 2 + 3) * (size_t)C * sizeof(float);
+}
+
+extern "C" int32_t pe_bn_finalize_bf16(const void* workspace, int32_t rows, int64_t M, int32_t C,
+                                       const float* gamma, const float* beta, float eps,
+                                       float momentum, float* running_mean, float* running_var,
+                                       float* mean, float* rstd, float* scale, float* shift,
+                                       pe_stream_t stream) {
+    int32_t rc = bn_check("pe_bn_finalize_bf16", M, C);
+    if (rc != PE_OK) return rc;
+    PE_REQUIRE(workspace && gamma && beta && mean && rstd && scale && shift && rows > 0,
+               PE_E_INVALID, "pe_bn_finalize_bf16: NULL pointer or no rows");
+    PE_REQUIRE((running_mean == nullptr) == (running_var == nullptr), PE_E_INVALID,
+               "pe_bn_finalize_bf16: give both running buffers or neither");
+    const BnFwdOut o{mean, rstd, scale, shift, running_mean, running_var};
+    const float unbias = M > 1 ? (float)((double)M / (double)(M - 1)) : 1.0f;
+    bn_fwd_finalize_kernel<<<(C + kFoldCh - 1) / kFoldCh, 256, 0, as_stream(stream)>>>(
+        static_cast<const float*>(workspace), rows, C, (float)(1.0 / (double)M), unbias, gamma, beta,
+        eps, momentum, o);
+    return check_launch("pe_bn_finalize_bf16");
 }
 
 extern "C" int32_t pe_bn_stats_bf16(const void* z, int64_t M, int32_t C, const float* gamma,

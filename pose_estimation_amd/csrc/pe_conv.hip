@@ -109,13 +109,31 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const uint16_t* __res
     *reinterpret_cast<uint4*>(y + ((b * Ho + oy) * Wo + ox) * (long)C + c8 * 8) = o;
 }
 
+// Request for the fused batch-norm statistics of a forward conv (training).
+struct StatReq {
+    void* workspace;
+    size_t bytes;
+    int32_t* rows_out;
+};
+
+static int32_t attach_stats(IgemmParams& p, const StatReq* sr, const char* what) {
+    if (sr == nullptr) return PE_OK;
+    PE_REQUIRE(sr->workspace && sr->rows_out, PE_E_INVALID, "%s: NULL statistics workspace", what);
+    PE_REQUIRE(aligned(sr->workspace, 16) && p.N % 8 == 0, PE_E_INVALID,
+               "%s: statistics need an aligned workspace and N %% 8 == 0", what);
+    p.stat_partial = static_cast<float*>(sr->workspace);
+    p.stat_capacity_rows = (long)(sr->bytes / ((size_t)2 * p.N * sizeof(float)));
+    p.stat_rows_out = sr->rows_out;
+    return PE_OK;
+}
+
 }  // namespace pe
 
 using namespace pe;
 
-extern "C" int32_t pe_conv2d_fwd_bf16(const pe_conv_desc* d, const void* x, const void* w,
-                                      const float* scale, const float* shift,
-                                      const void* residual, void* y, pe_stream_t stream) {
+static int32_t conv2d_fwd_impl(const pe_conv_desc* d, const void* x, const void* w,
+                               const float* scale, const float* shift, const void* residual,
+                               void* y, const StatReq* sr, pe_stream_t stream) {
     PE_REQUIRE(d != nullptr, PE_E_INVALID, "pe_conv2d_fwd_bf16: NULL descriptor");
     PE_REQUIRE(d->KH > 0 && d->KW > 0 && d->KH * d->KW <= kMaxTaps, PE_E_UNSUPPORTED,
                "pe_conv2d_fwd_bf16: filter %dx%d not supported", d->KH, d->KW);
@@ -155,13 +173,30 @@ extern "C" int32_t pe_conv2d_fwd_bf16(const pe_conv_desc* d, const void* x, cons
     p.ldc = d->Cout;
     p.relu = d->relu;
     p.out_mode = d->out_f32_nchw ? 1 : 0;
+    const int32_t rc = attach_stats(p, sr, "pe_conv2d_fwd_bf16");
+    if (rc != PE_OK) return rc;
     return igemm_launch(p, as_stream(stream), "pe_conv2d_fwd_bf16");
 }
 
-extern "C" int32_t pe_deconv4x4s2_fwd_bf16(int32_t B, int32_t H, int32_t W, int32_t Cin,
-                                           int32_t Cout, int32_t relu, const void* x,
-                                           const void* w_phases, const float* scale,
-                                           const float* shift, void* y, pe_stream_t stream) {
+extern "C" int32_t pe_conv2d_fwd_bf16(const pe_conv_desc* d, const void* x, const void* w,
+                                      const float* scale, const float* shift,
+                                      const void* residual, void* y, pe_stream_t stream) {
+    return conv2d_fwd_impl(d, x, w, scale, shift, residual, y, nullptr, stream);
+}
+
+extern "C" int32_t pe_conv2d_fwd_bnstats_bf16(const pe_conv_desc* d, const void* x, const void* w,
+                                              void* y, void* bn_workspace, size_t workspace_bytes,
+                                              int32_t* rows_out, pe_stream_t stream) {
+    PE_REQUIRE(d != nullptr && !d->relu && !d->out_f32_nchw, PE_E_INVALID,
+               "pe_conv2d_fwd_bnstats_bf16: needs a descriptor without ReLU and bf16 output");
+    const StatReq sr{bn_workspace, workspace_bytes, rows_out};
+    return conv2d_fwd_impl(d, x, w, nullptr, nullptr, nullptr, y, &sr, stream);
+}
+
+static int32_t deconv_fwd_impl(int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout,
+                               int32_t relu, const void* x, const void* w_phases,
+                               const float* scale, const float* shift, void* y,
+                               const StatReq* sr, pe_stream_t stream) {
     PE_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, PE_E_INVALID,
                "pe_deconv4x4s2_fwd_bf16: sizes must be positive");
     // the four output-parity phases run in one launch (gridDim.y = 4)
@@ -203,13 +238,31 @@ extern "C" int32_t pe_deconv4x4s2_fwd_bf16(int32_t B, int32_t H, int32_t W, int3
     p.osy = p.osx = 2;
     p.ldc = Cout;
     p.relu = relu;
+    const int32_t rc = attach_stats(p, sr, "pe_deconv4x4s2_fwd_bf16");
+    if (rc != PE_OK) return rc;
     return igemm_launch(p, as_stream(stream), "pe_deconv4x4s2_fwd_bf16");
 }
 
-extern "C" int32_t pe_stem7x7s2_fwd_bf16(int32_t B, int32_t H2, int32_t W2, int32_t Cout,
-                                         int32_t relu, const void* x_s2d, const void* w,
-                                         const float* scale, const float* shift, void* y,
-                                         pe_stream_t stream) {
+extern "C" int32_t pe_deconv4x4s2_fwd_bf16(int32_t B, int32_t H, int32_t W, int32_t Cin,
+                                           int32_t Cout, int32_t relu, const void* x,
+                                           const void* w_phases, const float* scale,
+                                           const float* shift, void* y, pe_stream_t stream) {
+    return deconv_fwd_impl(B, H, W, Cin, Cout, relu, x, w_phases, scale, shift, y, nullptr, stream);
+}
+
+extern "C" int32_t pe_deconv4x4s2_fwd_bnstats_bf16(int32_t B, int32_t H, int32_t W, int32_t Cin,
+                                                   int32_t Cout, const void* x,
+                                                   const void* w_phases, void* y,
+                                                   void* bn_workspace, size_t workspace_bytes,
+                                                   int32_t* rows_out, pe_stream_t stream) {
+    const StatReq sr{bn_workspace, workspace_bytes, rows_out};
+    return deconv_fwd_impl(B, H, W, Cin, Cout, 0, x, w_phases, nullptr, nullptr, y, &sr, stream);
+}
+
+static int32_t stem7_fwd_impl(int32_t B, int32_t H2, int32_t W2, int32_t Cout, int32_t relu,
+                              const void* x_s2d, const void* w, const float* scale,
+                              const float* shift, void* y, const StatReq* sr,
+                              pe_stream_t stream) {
     PE_REQUIRE(B > 0 && H2 > 0 && W2 > 0 && Cout > 0, PE_E_INVALID,
                "pe_stem7x7s2_fwd_bf16: sizes must be positive");
     IgemmParams p;
@@ -238,7 +291,24 @@ extern "C" int32_t pe_stem7x7s2_fwd_bf16(int32_t B, int32_t H2, int32_t W2, int3
     p.OW = W2;
     p.ldc = Cout;
     p.relu = relu;
+    const int32_t rc = attach_stats(p, sr, "pe_stem7x7s2_fwd_bf16");
+    if (rc != PE_OK) return rc;
     return igemm_launch(p, as_stream(stream), "pe_stem7x7s2_fwd_bf16");
+}
+
+extern "C" int32_t pe_stem7x7s2_fwd_bf16(int32_t B, int32_t H2, int32_t W2, int32_t Cout,
+                                         int32_t relu, const void* x_s2d, const void* w,
+                                         const float* scale, const float* shift, void* y,
+                                         pe_stream_t stream) {
+    return stem7_fwd_impl(B, H2, W2, Cout, relu, x_s2d, w, scale, shift, y, nullptr, stream);
+}
+
+extern "C" int32_t pe_stem7x7s2_fwd_bnstats_bf16(int32_t B, int32_t H2, int32_t W2, int32_t Cout,
+                                                 const void* x_s2d, const void* w, void* y,
+                                                 void* bn_workspace, size_t workspace_bytes,
+                                                 int32_t* rows_out, pe_stream_t stream) {
+    const StatReq sr{bn_workspace, workspace_bytes, rows_out};
+    return stem7_fwd_impl(B, H2, W2, Cout, 0, x_s2d, w, nullptr, nullptr, y, &sr, stream);
 }
 
 extern "C" int32_t pe_stem3x3s2_fwd_bf16(int32_t B, int32_t H2, int32_t W2, int32_t Cout,

@@ -41,6 +41,14 @@ struct IgemmParams {
     int16_t tap_dy[kMaxTaps];
     int16_t tap_dx[kMaxTaps];
     uint8_t tap_slot[kMaxTaps];  // position of each tap's Cin-block inside a weight row
+    // Fused batch-norm statistics (training): when stat_partial is set, every output tile also
+    // writes, per output channel, the sum and the sum of squares of its bf16-rounded values to
+    // stat_partial[(phase * stat_ntm + tile_m) * 2 + {0, 1}][N]; needs no scale/shift/residual/
+    // ReLU, bf16 NHWC output and equally sized phases.  stat_rows_out receives the row count.
+    float* stat_partial;
+    long stat_capacity_rows;
+    int32_t* stat_rows_out;   // host pointer
+    int stat_ntm;             // filled in by igemm_launch
     int32_t tap_info[kMaxTaps];  // dy | dx << 8 | slot << 16, packed by igemm_launch for the kernel
     // Optional phases (gridDim.y): phase i uses taps [ph_t0[i], ph_t0[i] + ph_T[i]), the row grid
     // ph_Ho[i] x ph_Wo[i], output offset (ph_ooy[i], ph_oox[i]) and weights w + ph_woff[i].

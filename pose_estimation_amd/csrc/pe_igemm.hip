@@ -333,7 +333,35 @@ __attribute__((amdgpu_waves_per_eu(MINB * WM / 2, MINB * WM / 2))) void igemm_ke
                     *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(p.y) + opix * p.ldc + n) = o;
                 }
             }
+            // Batch-norm statistics of what was just stored (the bf16-rounded tile): per column,
+            // sum and sum of squares over the tile's rows, in a fixed order.  Rows past M hold
+            // exact zeros (their inputs were the zero block and a BN conv has no bias).
+            constexpr int SG = NT / HALF;   // thread groups over rows
+            constexpr int RPG = BM / SG;    // rows per group
+            float* sred = cs + BM * CP;     // [SG][2][HALF]
+            if (p.stat_partial) {
+                const int colh = tid % HALF, grp = tid / HALF;
+                float s1 = 0.0f, s2 = 0.0f;
+#pragma unroll 8
+                for (int r = grp * RPG; r < (grp + 1) * RPG; ++r) {
+                    const float v =
+                        __uint_as_float(pack_bf16x2_bits(cs[r * CP + colh], 0.0f) << 16);
+                    s1 += v;
+                    s2 += v * v;
+                }
+                sred[(grp * 2 + 0) * HALF + colh] = s1;
+                sred[(grp * 2 + 1) * HALF + colh] = s2;
+            }
             __syncthreads();
+            if (p.stat_partial && tid < 2 * HALF) {
+                const int sidx = tid / HALF, colh = tid % HALF;
+                float t = 0.0f;
+#pragma unroll
+                for (int g2 = 0; g2 < SG; ++g2) t += sred[(g2 * 2 + sidx) * HALF + colh];
+                const int nn = n0 + half * HALF + colh;
+                if (nn < p.N)
+                    p.stat_partial[((long)(ph * p.stat_ntm + tile_m) * 2 + sidx) * p.N + nn] = t;
+            }
         }
         return;
     }
@@ -373,13 +401,21 @@ __attribute__((amdgpu_waves_per_eu(MINB * WM / 2, MINB * WM / 2))) void igemm_ke
 template <int BM, int BN, bool DB>
 static constexpr size_t lds_bytes() {
     const size_t ktile = (size_t)(BM + BN) * ROWB * (DB ? 2 : 1);
-    const size_t etile = (size_t)BM * (BN / 2 + 4) * sizeof(float);
+    // epilogue half tile + the per-group column sums of the fused batch-norm statistics
+    const size_t etile = (size_t)BM * (BN / 2 + 4) * sizeof(float) + 2 * 512 * sizeof(float);
     return ktile > etile ? ktile : etile;
 }
 
 template <int BM, int BN, int WM, bool DB, bool PF, int MINB>
-static void launch_cfg(const IgemmParams& p, long maxM, hipStream_t st) {
+static int32_t launch_cfg(IgemmParams& p, long maxM, hipStream_t st, const char* what) {
     const long ntm = (maxM + BM - 1) / BM;
+    p.stat_ntm = (int)ntm;
+    if (p.stat_partial) {
+        PE_REQUIRE(ntm * p.nphase <= p.stat_capacity_rows, PE_E_INVALID,
+                   "%s: statistics workspace holds %ld rows, %ld needed", what,
+                   (long)p.stat_capacity_rows, ntm * p.nphase);
+        if (p.stat_rows_out) *p.stat_rows_out = (int32_t)(ntm * p.nphase);
+    }
     const long ntn = (p.N + BN - 1) / BN;
     const dim3 grid((unsigned)(ntm * ntn), (unsigned)p.nphase);
     constexpr size_t lds = lds_bytes<BM, BN, DB>();
@@ -390,6 +426,7 @@ static void launch_cfg(const IgemmParams& p, long maxM, hipStream_t st) {
         (void)once;
     }
     igemm_kernel<BM, BN, WM, DB, PF, MINB><<<grid, WM * 128, lds, st>>>(p);
+    return check_launch(what);
 }
 
 int32_t igemm_launch(const IgemmParams& pin, hipStream_t st, const char* what) {
@@ -429,6 +466,16 @@ int32_t igemm_launch(const IgemmParams& pin, hipStream_t st, const char* what) {
         const long M = (long)p.B * p.ph_Ho[i] * p.ph_Wo[i];
         if (M > maxM) maxM = M;
     }
+    if (p.stat_partial) {
+        PE_REQUIRE(!p.scale && !p.shift && !p.res && !p.relu && p.out_mode == 0 &&
+                       (p.N & 7) == 0 && (p.ldc & 7) == 0,
+                   PE_E_UNSUPPORTED,
+                   "%s: fused statistics need a plain bf16 NHWC output (no scale, shift, residual "
+                   "or ReLU) and channel counts that are multiples of 8", what);
+        for (int i = 1; i < p.nphase; ++i)
+            PE_REQUIRE(p.ph_Ho[i] == p.ph_Ho[0] && p.ph_Wo[i] == p.ph_Wo[0], PE_E_UNSUPPORTED,
+                       "%s: fused statistics need equally sized phases", what);
+    }
     // the kernel's reciprocal-based index split needs quotients below 2^20
     PE_REQUIRE(p.B < (1 << 20) && maxM / p.B < (1L << 22), PE_E_UNSUPPORTED,
                "%s: batch or map size out of range", what);
@@ -458,8 +505,7 @@ int32_t igemm_launch(const IgemmParams& pin, hipStream_t st, const char* what) {
 #define PE_CFG(BM_, BN_, WM_, DB_, PF_, MINB_)                                        \
     if (bm == BM_ && bn == BN_ && wm == WM_ && db == (DB_ ? 1 : 0) && pf == (PF_ ? 1 : 0) && \
         minb == MINB_) {                                                               \
-        launch_cfg<BM_, BN_, WM_, DB_, PF_, MINB_>(p, maxM, st);                       \
-        return check_launch(what);                                                     \
+        return launch_cfg<BM_, BN_, WM_, DB_, PF_, MINB_>(p, maxM, st, what);          \
     }
     PE_CFG(128, 128, 2, false, false, 4)
     PE_CFG(128, 64, 2, false, false, 4)

@@ -138,6 +138,68 @@ def stem7x7s2(x_s2d: torch.Tensor, w: torch.Tensor, scale=None, shift=None, relu
     return out
 
 
+def conv2d_bnstats(x: torch.Tensor, w: torch.Tensor, ws: torch.Tensor, stride: int = 1,
+                   pad: int = 0, out: Optional[torch.Tensor] = None):
+    """z = conv(x, w) with the per-channel sums of z and z*z left in `ws` as one partial row per
+    GEMM tile; returns (z, rows) for bn_finalize."""
+    _check_act(x)
+    _need_gpu(w, ws, out)
+    B, H, W, Cin = x.shape
+    Cout, KH, KW, Cin2 = w.shape
+    if Cin2 != Cin or w.dtype != BF16 or not w.is_contiguous():
+        raise ValueError("w must be contiguous bfloat16 [Cout,KH,KW,Cin]")
+    Ho = (H + 2 * pad - KH) // stride + 1
+    Wo = (W + 2 * pad - KW) // stride + 1
+    if out is None:
+        out = torch.empty((B, Ho, Wo, Cout), dtype=BF16, device=x.device)
+    d = ConvDesc(B, H, W, Cin, Cout, KH, KW, stride, pad, 0, 0)
+    rows = ctypes.c_int32(0)
+    with torch.cuda.device(x.device):
+        check(lib().pe_conv2d_fwd_bnstats_bf16(ctypes.addressof(d), x.data_ptr(), w.data_ptr(),
+                                               out.data_ptr(), ws.data_ptr(), ws.numel(),
+                                               ctypes.byref(rows), _stream(x)))
+    return out, rows.value
+
+
+def deconv4x4s2_bnstats(x: torch.Tensor, w_phases: torch.Tensor, ws: torch.Tensor,
+                        out: Optional[torch.Tensor] = None):
+    """deconv4x4s2 without an epilogue, plus the statistics partials (see conv2d_bnstats)."""
+    _check_act(x)
+    _need_gpu(w_phases, ws, out)
+    B, H, W, Cin = x.shape
+    _, Cout, _, _ = w_phases.shape
+    if tuple(w_phases.shape) != (4, Cout, 4, Cin) or w_phases.dtype != BF16:
+        raise ValueError("w_phases must be bfloat16 [4,Cout,4,Cin]")
+    if out is None:
+        out = torch.empty((B, 2 * H, 2 * W, Cout), dtype=BF16, device=x.device)
+    rows = ctypes.c_int32(0)
+    with torch.cuda.device(x.device):
+        check(lib().pe_deconv4x4s2_fwd_bnstats_bf16(B, H, W, Cin, Cout, x.data_ptr(),
+                                                    w_phases.data_ptr(), out.data_ptr(),
+                                                    ws.data_ptr(), ws.numel(), ctypes.byref(rows),
+                                                    _stream(x)))
+    return out, rows.value
+
+
+def stem7x7s2_bnstats(x_s2d: torch.Tensor, w: torch.Tensor, ws: torch.Tensor,
+                      out: Optional[torch.Tensor] = None):
+    """stem7x7s2 without an epilogue, plus the statistics partials (see conv2d_bnstats)."""
+    _check_act(x_s2d, "x_s2d")
+    _need_gpu(w, ws, out)
+    B, H2, W2, C = x_s2d.shape
+    Cout = w.shape[0]
+    if C != 16 or tuple(w.shape) != (Cout, 4, 64) or w.dtype != BF16:
+        raise ValueError("stem expects x_s2d [...,16] and w bfloat16 [Cout,4,64]")
+    if out is None:
+        out = torch.empty((B, H2, W2, Cout), dtype=BF16, device=x_s2d.device)
+    rows = ctypes.c_int32(0)
+    with torch.cuda.device(x_s2d.device):
+        check(lib().pe_stem7x7s2_fwd_bnstats_bf16(B, H2, W2, Cout, x_s2d.data_ptr(), w.data_ptr(),
+                                                  out.data_ptr(), ws.data_ptr(), ws.numel(),
+                                                  ctypes.byref(rows), _stream(x_s2d)))
+    return out, rows.value
+
+
 IMAGENET_MEAN = (0.485, 0.456, 0.406)
 IMAGENET_STD = (0.229, 0.224, 0.225)
 
@@ -425,6 +487,20 @@ def bn_stats(z: torch.Tensor, gamma, beta, eps: float, momentum: float, running_
                                      momentum, _ptr(running_mean), _ptr(running_var),
                                      out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(),
                                      out[3].data_ptr(), ws.data_ptr(), _stream(z)))
+    return out[0], out[1], out[2], out[3]
+
+
+def bn_finalize(ws: torch.Tensor, rows: int, M: int, C: int, gamma, beta, eps: float,
+                momentum: float, running_mean, running_var, out=None):
+    """Second half of bn_stats for partial sums a *_bnstats conv left in `ws`."""
+    _need_gpu(ws, gamma, beta, running_mean, running_var, out)
+    if out is None:
+        out = torch.empty((4, C), dtype=torch.float32, device=ws.device)
+    with torch.cuda.device(ws.device):
+        check(lib().pe_bn_finalize_bf16(ws.data_ptr(), int(rows), M, C, gamma.data_ptr(),
+                                        beta.data_ptr(), eps, momentum, _ptr(running_mean),
+                                        _ptr(running_var), out[0].data_ptr(), out[1].data_ptr(),
+                                        out[2].data_ptr(), out[3].data_ptr(), _stream(ws)))
     return out[0], out[1], out[2], out[3]
 
 

@@ -92,7 +92,10 @@ class TrainablePoseResNet(PoseResNet):
 
     def _workspace(self, z: torch.Tensor) -> torch.Tensor:
         C = z.shape[3]
-        need = pnn.lib().pe_bn_workspace_bytes(z.numel() // C, C)
+        return self._workspace_for(z.numel() // C, C)
+
+    def _workspace_for(self, M: int, C: int) -> torch.Tensor:
+        need = pnn.lib().pe_bn_workspace_bytes(M, C)
         if self._ws is None or self._ws.numel() < need:
             self._ws = torch.empty(max(need, 1 << 24), dtype=torch.uint8, device=self.device)
         return self._ws
@@ -107,26 +110,33 @@ class TrainablePoseResNet(PoseResNet):
         return self.view(self.grads, name)
 
     # ------------------------------------------------------------------ forward (batch stats)
-    def _bn(self, c: ConvSpec, z: torch.Tensor, residual=None, relu=True) -> torch.Tensor:
-        _, _, scale, shift = pnn.bn_stats(z, self._gamma(c), self._beta(c), BN_EPS, self.bn_momentum,
-                                          self.bn_mean[c.name], self.bn_var[c.name],
-                                          self._workspace(z), out=self.bn_buf[c.name])
+    def _bn(self, c: ConvSpec, z: torch.Tensor, rows: int, residual=None, relu=True) -> torch.Tensor:
+        """Normalises z with the batch statistics its conv left in the workspace as `rows`
+        partial rows.  The workspace is shared, so this must run before the next conv."""
+        C = z.shape[3]
+        _, _, scale, shift = pnn.bn_finalize(self._ws, rows, z.numel() // C, C, self._gamma(c),
+                                             self._beta(c), BN_EPS, self.bn_momentum,
+                                             self.bn_mean[c.name], self.bn_var[c.name],
+                                             out=self.bn_buf[c.name])
         return pnn.bn_apply(z, scale, shift, residual, relu)
+
+    def _conv_bn(self, c: ConvSpec, x: torch.Tensor, stride=1, pad=0, residual=None, relu=True):
+        B, H, W, _ = x.shape
+        k = c.k
+        M = B * ((H + 2 * pad - k) // stride + 1) * ((W + 2 * pad - k) // stride + 1)
+        z, rows = pnn.conv2d_bnstats(x, self.w(c), self._workspace_for(M, c.cout), stride, pad)
+        return z, self._bn(c, z, rows, residual, relu)
 
     def block_forward(self, b, x: torch.Tensor) -> dict:
         """One bottleneck block with batch statistics; returns everything backward needs."""
-        z1 = pnn.conv2d(x, self.w(b.c1))
-        a1 = self._bn(b.c1, z1)
-        z2 = pnn.conv2d(a1, self.w(b.c2), stride=b.c2.stride, pad=1)
-        a2 = self._bn(b.c2, z2)
-        z3 = pnn.conv2d(a2, self.w(b.c3))
+        z1, a1 = self._conv_bn(b.c1, x)
+        z2, a2 = self._conv_bn(b.c2, a1, stride=b.c2.stride, pad=1)
         zd = None
         if b.down:
-            zd = pnn.conv2d(x, self.w(b.down), stride=b.down.stride)
-            idn = self._bn(b.down, zd, relu=False)
+            zd, idn = self._conv_bn(b.down, x, stride=b.down.stride, relu=False)
         else:
             idn = x
-        out = self._bn(b.c3, z3, residual=idn, relu=True)
+        z3, out = self._conv_bn(b.c3, a2, residual=idn, relu=True)
         return dict(x=x, z1=z1, a1=a1, z2=z2, a2=a2, z3=z3, zd=zd, out=out)
 
     def block_backward(self, b, s: dict, dout: torch.Tensor) -> torch.Tensor:
@@ -157,8 +167,9 @@ class TrainablePoseResNet(PoseResNet):
         return pnn.conv2d_bwd_data(dz1, self.wt[b.c1.name], hw_in, 1, 1, 0, residual=res)
 
     def deconv_forward(self, d, x: torch.Tensor) -> dict:
-        z = pnn.deconv4x4s2(x, self.w(d))
-        return dict(x=x, z=z, a=self._bn(d, z))
+        B, H, W, _ = x.shape
+        z, rows = pnn.deconv4x4s2_bnstats(x, self.w(d), self._workspace_for(4 * B * H * W, d.cout))
+        return dict(x=x, z=z, a=self._bn(d, z, rows))
 
     def deconv_backward(self, d, s: dict, da: torch.Tensor) -> torch.Tensor:
         dz, _ = self._bn_bwd(d, da, s["a"], s["z"])
@@ -173,8 +184,9 @@ class TrainablePoseResNet(PoseResNet):
         stem, blocks, deconvs, final = self.specs
         sv: dict = {"blocks": [], "deconvs": []}
         xs = x_s2d if x_s2d is not None else pnn.preprocess_u8(images_u8)
-        z0 = pnn.stem7x7s2(xs, self.w(stem), None, None, relu=False)
-        a0 = self._bn(stem, z0)
+        z0, rows = pnn.stem7x7s2_bnstats(xs, self.w(stem),
+                                         self._workspace_for(xs.numel() // 16, stem.cout))
+        a0 = self._bn(stem, z0, rows)
         x, pool_idx = pnn.maxpool3x3s2(a0, want_index=True)
         sv.update(xs=xs, z0=z0, a0=a0, pool_idx=pool_idx)
         for b in blocks:

@@ -226,6 +226,69 @@ def test_batch_norm_forward_backward(shape):
     assert torch.equal(dz, dz2)
 
 
+@pytest.mark.parametrize("cfg", [
+    # kind, B, H, W, Cin, Cout, k, stride, pad
+    ("conv", 4, 16, 12, 64, 64, 1, 1, 0),
+    ("conv", 3, 17, 13, 64, 128, 3, 2, 1),      # ragged last tile
+    ("conv", 64, 16, 12, 256, 512, 1, 1, 0),    # 128-pixel tiles
+    ("conv", 2, 8, 6, 512, 2048, 1, 1, 0),
+    ("conv", 32, 64, 48, 64, 64, 3, 1, 1),
+    ("deconv", 3, 8, 6, 64, 256, 4, 2, 1),
+    ("stem", 4, 32, 24, 16, 64, 7, 2, 3),
+])
+def test_conv_with_fused_batch_statistics(cfg):
+    """The *_bnstats convs store the same z as the plain convs and their partial rows finalize
+    to the statistics pe_bn_stats_bf16 computes from z (the two sum in different orders)."""
+    kind, B, H, W, Cin, Cout, k, stride, pad = cfg
+    g = torch.Generator().manual_seed(61 + Cout + H)
+    x = (rnd((B, H, W, Cin), g)).to(BF16).cuda()
+    gamma = (torch.rand(Cout, generator=g) + 0.5).cuda()
+    beta = (torch.randn(Cout, generator=g) * 0.2).cuda()
+    if kind == "conv":
+        w = (rnd((Cout, k, k, Cin), g) * (2.0 / (k * k * Cin)) ** 0.5).to(BF16).cuda()
+        z_ref = pnn.conv2d(x, w, stride=stride, pad=pad)
+        M = z_ref.numel() // Cout
+        ws = pnn.bn_workspace(M, Cout, "cuda")
+        z, rows = pnn.conv2d_bnstats(x, w, ws, stride, pad)
+    elif kind == "deconv":
+        w = (rnd((4, Cout, 4, Cin), g) * (2.0 / (4 * Cin)) ** 0.5).to(BF16).cuda()
+        z_ref = pnn.deconv4x4s2(x, w)
+        M = z_ref.numel() // Cout
+        ws = pnn.bn_workspace(M, Cout, "cuda")
+        z, rows = pnn.deconv4x4s2_bnstats(x, w, ws)
+    else:
+        w = (rnd((Cout, 4, 64), g) * 0.1).to(BF16).cuda()
+        z_ref = pnn.stem7x7s2(x, w, None, None, relu=False)
+        M = z_ref.numel() // Cout
+        ws = pnn.bn_workspace(M, Cout, "cuda")
+        z, rows = pnn.stem7x7s2_bnstats(x, w, ws)
+    assert torch.equal(z, z_ref) and rows > 0
+    rm1, rv1 = torch.zeros(Cout, device="cuda"), torch.ones(Cout, device="cuda")
+    rm2, rv2 = rm1.clone(), rv1.clone()
+    got = pnn.bn_finalize(ws, rows, M, Cout, gamma, beta, 1e-5, 0.1, rm1, rv1)
+    got = [t.clone() for t in got]
+    ws2 = pnn.bn_workspace(M, Cout, "cuda")
+    want = pnn.bn_stats(z_ref, gamma, beta, 1e-5, 0.1, rm2, rv2, ws2)
+    zf = z_ref.float().reshape(M, Cout).double()
+    assert torch.allclose(got[0].cpu().double(), zf.mean(0).cpu(), atol=2e-6, rtol=1e-5)
+    for a, b in zip(got, want):
+        assert torch.allclose(a, b, rtol=2e-4, atol=2e-6)
+    assert torch.allclose(rm1, rm2, rtol=1e-4, atol=1e-6) and torch.allclose(rv1, rv2, rtol=2e-4)
+    # ordered sums: a second run gives the same bits
+    if kind == "conv":
+        pnn.conv2d_bnstats(x, w, ws, stride, pad)
+        again = pnn.bn_finalize(ws, rows, M, Cout, gamma, beta, 1e-5, 0.1, None, None)
+        assert all(torch.equal(a, b) for a, b in zip(again, got))
+
+
+def test_fused_statistics_reject_an_epilogue_and_a_small_workspace():
+    x = torch.zeros((2, 8, 8, 64), dtype=BF16, device="cuda")
+    w = torch.zeros((64, 1, 1, 64), dtype=BF16, device="cuda")
+    tiny = torch.empty(64, dtype=torch.uint8, device="cuda")
+    with pytest.raises(Exception, match="workspace|capacity|rows"):
+        pnn.conv2d_bnstats(x, w, tiny)
+
+
 def test_maxpool_backward_with_ties():
     g = torch.Generator().manual_seed(53)
     x = torch.relu(rnd((3, 16, 12, 64), g))  # about half the cells are exactly 0: many ties
