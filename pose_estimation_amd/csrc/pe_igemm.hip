@@ -258,8 +258,36 @@ __attribute__((amdgpu_waves_per_eu(MINB * WM / 2, MINB * WM / 2))) void igemm_ke
         float* cs = reinterpret_cast<float*>(smem);
         const int chunk = tid % CPR;
         const int prow = tid / CPR;
+        // output pixel of each store pass (the same for both column halves); -1 = no store
+        long opixs[NPASS];
+#pragma unroll
+        for (int pass = 0; pass < NPASS; ++pass) {
+            const int pr = prow + pass * RPP;
+            const long m = m0 + pr;
+            long opix = m;
+            if (!identity) {
+                int bb, rem, oy, ox;
+                fast_divmod((int)(m < M ? m : 0), HoWo, inv_howo, bb, rem);
+                fast_divmod(rem, Wo, inv_wo, oy, ox);
+                opix = (long)bb * OHW + (oy * p.osy + ooy) * p.OW + ox * p.osx + oox;
+            }
+            opixs[pass] = (pr < BM && m < M) ? opix : -1;
+        }
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
+            // the residual rows of every pass are requested before the tile is staged, so the
+            // loads are in flight across the LDS round trip instead of one per pass
+            const int nres = n0 + half * HALF + chunk * 8;
+            uint4 rres[NPASS];
+            if (p.res) {
+#pragma unroll
+                for (int pass = 0; pass < NPASS; ++pass) {
+                    rres[pass] = make_uint4(0u, 0u, 0u, 0u);
+                    if (opixs[pass] >= 0 && nres < p.N)
+                        rres[pass] =
+                            *reinterpret_cast<const uint4*>(p.res + opixs[pass] * p.ldc + nres);
+                }
+            }
             if (wave_n == half) {
 #pragma unroll
                 for (int a = 0; a < TN; ++a) {
@@ -296,20 +324,13 @@ __attribute__((amdgpu_waves_per_eu(MINB * WM / 2, MINB * WM / 2))) void igemm_ke
 #pragma unroll
                 for (int pass = 0; pass < NPASS; ++pass) {
                     const int pr = prow + pass * RPP;
-                    const long m = m0 + pr;
-                    if (pr >= BM || m >= M) break;
-                    long opix = m;
-                    if (!identity) {
-                        int bb, rem, oy, ox;
-                        fast_divmod((int)m, HoWo, inv_howo, bb, rem);
-                        fast_divmod(rem, Wo, inv_wo, oy, ox);
-                        opix = (long)bb * OHW + (oy * p.osy + ooy) * p.OW + ox * p.osx + oox;
-                    }
+                    const long opix = opixs[pass];
+                    if (opix < 0) continue;
                     const f32x4 v0 = *reinterpret_cast<const f32x4*>(cs + pr * CP + chunk * 8);
                     const f32x4 v1 = *reinterpret_cast<const f32x4*>(cs + pr * CP + chunk * 8 + 4);
                     float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
                     if (p.res) {
-                        const uint4 rv = *reinterpret_cast<const uint4*>(p.res + opix * p.ldc + n);
+                        const uint4 rv = rres[pass];
                         const uint32_t u[4] = {rv.x, rv.y, rv.z, rv.w};
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
