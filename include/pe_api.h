@@ -395,6 +395,38 @@ int32_t pe_bn_finalize_bf16(const void* workspace, int32_t rows, int64_t M, int3
                             float* running_mean, float* running_var, float* mean, float* rstd,
                             float* scale, float* shift, pe_stream_t stream);
 
+/* ------------------------------------------------------------------------
+ * Detection branch: per-anchor targets from ground-truth boxes, and the loss on them.
+ * Replaces: utils/bboxes.py (PoseEstimation.pyproj:35; absent).  Visible in the reference: 1500 =
+ * 20*20*3 + 10*10*3 anchors per image with `classes`, `weights`, `regs` labels
+ * (test.ipynb:423-464, 504-507), one positive anchor per person (test.ipynb:538-541) and
+ * `regs` rows that are corner boxes in [0, 1] (test.ipynb:571-572).
+ *   anchors      [A,4] float32 (ymin, xmin, ymax, xmax), any order of anchors
+ *   boxes        [B,G,4] float32 corner boxes; box_classes [B,G] int32, <= 0 marks an empty
+ *                slot; G <= 64
+ *   Each labelled box claims the anchor it overlaps most (lowest anchor on ties, lowest box on
+ *   contested anchors).  With pos_iou <= 1, anchors whose best IoU >= pos_iou also take their
+ *   best box.  Matched: class of the box, weight 1, regs = the box, match = box index.
+ *   Unmatched: class 0, regs 0, match -1, weight 1, or 0 when the best IoU >= ignore_iou.
+ * Results are exact (fixed float32 operation order).
+ * ---------------------------------------------------------------------- */
+int32_t pe_anchor_assign_f32(const float* anchors, int32_t A, const float* boxes,
+                             const int32_t* box_classes, int32_t B, int32_t G, float pos_iou,
+                             float ignore_iou, float* classes, float* weights, float* regs,
+                             int32_t* match, pe_stream_t stream);
+
+/* Loss of the detection branch (model/base_model.py, PoseEstimation.pyproj:30; absent):
+ *   cls = sum_a weights * BCEwithLogits(logit, classes > 0) / N
+ *   reg = sum_{positive a} sum_4 huber_1(reg_pred - regs) / N,  N = max(1, positives in batch)
+ *   loss4 = {cls + reg_weight*reg, cls, reg, positives}; grad_logit [B,A] and grad_reg [B,A,4]
+ *   (either may be NULL) receive d(loss4[0]).  Sums run in a fixed order (bit-stable).
+ * workspace: pe_box_loss_workspace_bytes(B). */
+size_t pe_box_loss_workspace_bytes(int32_t B);
+int32_t pe_box_loss_fwd_bwd(const float* logit, const float* reg_pred, const float* classes,
+                            const float* weights, const float* regs, int32_t B, int32_t A,
+                            float reg_weight, float* loss4, float* grad_logit, float* grad_reg,
+                            void* workspace, pe_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

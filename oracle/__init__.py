@@ -12,6 +12,8 @@ only reference-held facts they are pinned against are notebook outputs:
   * heat-map support of test.ipynb:606-614 (five 3x3 blocks on a 40x40x3 map),
   * vector-map support of test.ipynb:634-653 (116 non-zero cells of the 40x40x8 map
     of the same label, including a keypoint whose centre is off the map),
+  * 1500 = 20*20*3 + 10*10*3 anchors, one positive anchor per person, corner-box `regs`
+    (test.ipynb:423-572),
   * stride 8 / 320x320 -> 40x40 (test.ipynb:919, 928, 1010),
   * Adam hyper-parameters (test.ipynb:1001-1008).
 """
@@ -23,6 +25,10 @@ from .numpy_oracle import (  # noqa: F401
     augment_u8,
     transform_joints,
     vecmap_loss_fwd_bwd,
+    ssd_anchors,
+    box_iou,
+    anchor_assign,
+    box_loss_fwd_bwd,
     mse_fwd_bwd,
     adam_step,
     sgd_step,

@@ -392,3 +392,114 @@ def sgd_step(p, mom, g, lr, momentum, grad_scale=1.0):
     mom2 = ((F32(momentum) * mom).astype(F32) + g).astype(F32)
     p2 = (p - (F32(lr) * mom2).astype(F32)).astype(F32)
     return p2, mom2, f32_to_bf16_bits(p2)
+
+
+# --------------------------------------------------------------------------- detection branch
+def ssd_anchors(levels=((20, 20), (10, 10)), scales=(0.35, 0.75), ratios=(0.5, 1.0, 2.0)):
+    """Anchor boxes (ymin, xmin, ymax, xmax) in normalised image coordinates, float32 [A, 4].
+
+    Order: level by level, then row, column, aspect ratio, which is the [20, 20, 3] + [10, 10, 3]
+    = 1500 layout the reference's labels are reshaped with (test.ipynb:423-464).  Box height is
+    scale / sqrt(ratio) and width scale * sqrt(ratio), centred on the cell centre.  The scale and
+    ratio values themselves are not visible in the reference.
+    """
+    out = []
+    for (fh, fw), s in zip(levels, scales):
+        for y in range(fh):
+            for x in range(fw):
+                cy = F32((F32(y) + F32(0.5)) / F32(fh))
+                cx = F32((F32(x) + F32(0.5)) / F32(fw))
+                for r in ratios:
+                    sq = F32(np.sqrt(F32(r)))
+                    hh = F32(F32(s) / sq) * F32(0.5)
+                    hw = F32(F32(s) * sq) * F32(0.5)
+                    out.append((cy - hh, cx - hw, cy + hh, cx + hw))
+    return np.asarray(out, dtype=F32)
+
+
+def box_iou(a, g) -> np.float32:
+    """IoU of two corner boxes in float32, operations in the order the kernel uses."""
+    iy0, ix0 = max(a[0], g[0]), max(a[1], g[1])
+    iy1, ix1 = min(a[2], g[2]), min(a[3], g[3])
+    ih = max(F32(iy1 - iy0), F32(0))
+    iw = max(F32(ix1 - ix0), F32(0))
+    inter = F32(ih * iw)
+    area_a = F32(F32(a[2] - a[0]) * F32(a[3] - a[1]))
+    area_g = F32(F32(g[2] - g[0]) * F32(g[3] - g[1]))
+    union = F32(F32(area_a + area_g) - inter)
+    return F32(inter / union) if union > 0 else F32(0)
+
+
+def anchor_assign(anchors, boxes, box_classes, pos_iou: float = 2.0, ignore_iou: float = 0.5):
+    """Per-anchor detection targets.
+
+    anchors [A,4]; boxes [B,G,4] corner boxes; box_classes [B,G] int (0 = padding slot).
+    Returns classes [B,A] f32, weights [B,A] f32, regs [B,A,4] f32, match [B,A] int32.
+
+    Every labelled box claims the anchor it overlaps most (lowest anchor index on ties; a box
+    that overlaps no anchor claims none; the lowest box index wins a contested anchor).  With
+    pos_iou <= 1, anchors whose best overlap reaches pos_iou also take their best box (lowest
+    box index on ties).  A matched anchor gets that box's class, weight 1 and the box itself as
+    regression target: the reference's labels show exactly one positive anchor per person and
+    `regs` rows that are corner boxes in [0, 1] (test.ipynb:504-572).  Unmatched anchors are
+    background (class 0, regs 0) with weight 1, or weight 0 when their best overlap reaches
+    ignore_iou.
+    """
+    anchors = np.asarray(anchors, F32)
+    boxes = np.asarray(boxes, F32)
+    box_classes = np.asarray(box_classes)
+    B, G = box_classes.shape
+    A = anchors.shape[0]
+    classes = np.zeros((B, A), F32)
+    weights = np.ones((B, A), F32)
+    regs = np.zeros((B, A, 4), F32)
+    match = np.full((B, A), -1, np.int32)
+    for b in range(B):
+        best_iou = np.zeros(A, F32)
+        best_g = np.full(A, -1, np.int32)
+        claim = np.full(G, -1, np.int32)
+        for g in range(G):
+            if box_classes[b, g] <= 0:
+                continue
+            top = F32(0)
+            for a in range(A):
+                v = box_iou(anchors[a], boxes[b, g])
+                if v > best_iou[a]:
+                    best_iou[a], best_g[a] = v, g
+                if v > top:
+                    top, claim[g] = v, a
+        for a in range(A):
+            if pos_iou <= 1.0 and best_g[a] >= 0 and best_iou[a] >= F32(pos_iou):
+                match[b, a] = best_g[a]
+            elif best_iou[a] >= F32(ignore_iou):
+                weights[b, a] = 0.0
+        for g in range(G - 1, -1, -1):
+            if claim[g] >= 0:
+                match[b, claim[g]] = g
+        for a in range(A):
+            g = match[b, a]
+            if g >= 0:
+                classes[b, a] = F32(box_classes[b, g])
+                weights[b, a] = 1.0
+                regs[b, a] = boxes[b, g]
+    return classes, weights, regs, match
+
+
+def box_loss_fwd_bwd(logit, reg_pred, classes, weights, regs, reg_weight: float = 1.0):
+    """Detection loss and gradients in float64 (the kernel sums in float32: compare with a
+    tolerance).  Objectness: weighted sigmoid cross-entropy against (classes > 0); boxes: Huber
+    (delta 1) on the four coordinates of positive anchors; both divided by max(1, positives).
+    Returns (total, cls, reg, grad_logit, grad_reg)."""
+    x = np.asarray(logit, np.float64)
+    t = (np.asarray(classes) > 0).astype(np.float64)
+    w = np.asarray(weights, np.float64)
+    pos = t * (w > 0)
+    n = max(1.0, float(pos.sum()))
+    bce = np.maximum(x, 0) - x * t + np.log1p(np.exp(-np.abs(x)))
+    cls = float((w * bce).sum() / n)
+    g_logit = w * (1.0 / (1.0 + np.exp(-x)) - t) / n
+    d = np.asarray(reg_pred, np.float64) - np.asarray(regs, np.float64)
+    hub = np.where(np.abs(d) < 1.0, 0.5 * d * d, np.abs(d) - 0.5)
+    reg = float((pos[..., None] * hub).sum() / n)
+    g_reg = pos[..., None] * np.clip(d, -1.0, 1.0) * (reg_weight / n)
+    return cls + reg_weight * reg, cls, reg, g_logit.astype(F32), g_reg.astype(F32)

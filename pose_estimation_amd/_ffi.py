@@ -144,6 +144,12 @@ SIGNATURES = {
         c_int32, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p],
     ),
     "pe_mul_f32": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p]),
+    "pe_anchor_assign_f32": (
+        c_int32, [c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_int32, c_float, c_float,
+                  c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "pe_box_loss_workspace_bytes": (c_size_t, [c_int32]),
+    "pe_box_loss_fwd_bwd": (
+        c_int32, [c_void_p] * 5 + [c_int32, c_int32, c_float] + [c_void_p] * 5),
     "pe_bn_workspace_bytes": (c_size_t, [c_int64, c_int32]),
     "pe_conv2d_fwd_bnstats_bf16": (
         c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
