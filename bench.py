@@ -390,6 +390,52 @@ class MobileNetInfer(Workload):
                 "sample": f"torch-CPU float32 oracle forward, batch 8, median of 3 ({med:.2f} s)"}
 
 
+class HRNetInfer(Workload):
+    """BASELINE configs[4] (forward part): HRNet-W32-style multi-branch backbone at 384x288 ->
+    96x72 heat maps, batch 64, bf16, preprocessing and decode included."""
+    name = "hrnet_w32_pose_infer_384x288_b64_bf16"
+    batch = 64
+    heatmap = (96, 72)
+    dtype = "bf16"
+    bound = "mfma"
+    kernel = "igemm_kernel + fuse_upsample_add_kernel (all launches of one forward)"
+    peak = 2500.0
+
+    def setup(self, device):
+        from pose_estimation_amd import hrnet
+
+        self.net = hrnet.PoseHRNet(device)
+        self.net.load_state(hrnet.init_state(self.net.spec, seed=3))
+        self.flops_per_step = 2.0 * hrnet.forward_macs(self.net.spec, 384, 288) * self.batch
+        self.imgs = [torch.from_numpy(synthetic.images_u8(self.batch, 384, 288, seed=1 + i)).to(device)
+                     for i in range(2)]
+
+    def step(self, i):
+        pe.decode(self.net.predict(self.imgs[i % 2]))
+
+    def roofline(self, kern_ms):
+        ach = self.flops_per_step / (kern_ms * 1e-3) / 1e12
+        return {"bound": "mfma", "kernel": self.kernel, "achieved": ach, "peak": self.peak,
+                "unit": "TFLOP/s", "frac": ach / self.peak,
+                "flops_per_step": self.flops_per_step, "step_ms": kern_ms, "traffic": None}
+
+    def cpu_baseline(self):
+        from oracle import torch_oracle as to
+        from pose_estimation_amd import hrnet
+        from pose_estimation_amd import nn as pnn
+
+        spec = hrnet.hrnet_specs()
+        state = hrnet.init_state(spec, seed=3)
+        img = synthetic.images_u8(4, 384, 288, seed=1)
+        to.hrnet_pose_forward(spec, state, img[:1], pnn.IMAGENET_MEAN, pnn.IMAGENET_STD)
+        t0 = time.perf_counter()
+        to.hrnet_pose_forward(spec, state, img, pnn.IMAGENET_MEAN, pnn.IMAGENET_STD)
+        dt = time.perf_counter() - t0
+        return {"value": 4 / dt, "unit": "images/s", "cores": torch.get_num_threads(),
+                "kind": "port",
+                "sample": f"torch-CPU float32 oracle forward, batch 4, one run ({dt:.2f} s)"}
+
+
 class Train(Workload):
     """BASELINE configs[3]: full training step (forward with batch statistics, fused target
     render + masked MSE, backward, gradient all-reduce when N > 1, fused Adam), batch 64 per GPU."""
@@ -453,7 +499,7 @@ class Train(Workload):
 
 WORKLOADS = {"decode": Decode, "render": Render, "mse": Mse, "mse_fused": MseFused, "adam": Adam,
              "vecmap": VecRender, "vecmap_loss": VecLoss, "mobilenet": MobileNetInfer,
-             "augment": Augment,
+             "augment": Augment, "hrnet": HRNetInfer,
              "infer": Infer, "train": Train}
 
 

@@ -203,6 +203,10 @@ int32_t pe_sgd_step(float* p, float* mom, const float* grad, uint16_t* p_bf16,
  * Accumulation is fp32.  Epilogue: y = acc*scale[c] + shift[c] (+ residual)
  * (-> ReLU) -> bf16; scale/shift/residual may be NULL.
  * Cin must be a multiple of 64, Cout a multiple of 4 (except f32-NCHW output).
+ * Narrow inputs (pe_conv2d_fwd_bf16 only): Cin of 8, 16 or 32 is accepted with weights
+ * packed [Cout][KH][ceil(KW/P)][P*Cin], P = 64/Cin: run c of a filter row holds taps
+ * kw = c*P .. c*P+P-1 pixel by pixel (zero where kw >= KW), because P horizontally
+ * adjacent NHWC pixels are one contiguous 64-element run.
  * ---------------------------------------------------------------------- */
 typedef struct pe_conv_desc {
     int32_t B, H, W, Cin;       /* input  [B,H,W,Cin] */
@@ -394,6 +398,18 @@ int32_t pe_bn_finalize_bf16(const void* workspace, int32_t rows, int64_t M, int3
                             const float* gamma, const float* beta, float eps, float momentum,
                             float* running_mean, float* running_var, float* mean, float* rstd,
                             float* scale, float* shift, pe_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * Multi-resolution fusion (HRNet-style exchange units of the 384x288 configuration; the
+ * reference itself names only nets/mobilenet_v2.py, PoseEstimation.pyproj:32):
+ *   y = relu?( base + sum_i nearest_upsample(low_i, 2^log2_factor_i) )
+ * base (may be NULL) and y are bf16 NHWC [B,H,W,C]; low_i are bf16 NHWC
+ * [B, H >> f_i, W >> f_i, C].  low_host / log2_factor_host are HOST arrays of n_low <= 3
+ * device pointers / exponents (1..5).  Summed in float32 in argument order, rounded once.
+ * ---------------------------------------------------------------------- */
+int32_t pe_fuse_upsample_add_bf16(const void* base, int32_t n_low, const void* const* low_host,
+                                  const int32_t* log2_factor_host, int32_t B, int32_t H,
+                                  int32_t W, int32_t C, int32_t relu, void* y, pe_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * Detection branch: per-anchor targets from ground-truth boxes, and the loss on them.

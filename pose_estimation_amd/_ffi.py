@@ -144,6 +144,9 @@ SIGNATURES = {
         c_int32, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p],
     ),
     "pe_mul_f32": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p]),
+    "pe_fuse_upsample_add_bf16": (
+        c_int32, [c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32,
+                  c_int32, c_void_p, c_void_p]),
     "pe_anchor_assign_f32": (
         c_int32, [c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_int32, c_float, c_float,
                   c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

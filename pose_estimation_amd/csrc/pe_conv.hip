@@ -162,12 +162,32 @@ static int32_t conv2d_fwd_impl(const pe_conv_desc* d, const void* x, const void*
     p.Wo = Wo;
     p.sy = p.sx = d->stride;
     p.N = d->Cout;
-    p.T = d->KH * d->KW;
-    for (int kh = 0; kh < d->KH; ++kh)
-        for (int kw = 0; kw < d->KW; ++kw) {
-            p.tap_dy[kh * d->KW + kw] = (int16_t)(kh - d->pad);
-            p.tap_dx[kh * d->KW + kw] = (int16_t)(kw - d->pad);
-        }
+    if (d->Cin == 8 || d->Cin == 16 || d->Cin == 32) {
+        // Narrow inputs: one 64-element K run covers P = 64/Cin horizontally adjacent pixels
+        // (contiguous in NHWC), so a filter row of KW taps becomes ceil(KW/P) runs.  Weights
+        // arrive packed to match, [Cout][KH][ceil(KW/P)][P*Cin], zero where a run reaches past
+        // the filter; each 8-channel load checks its own pixel against the image border.
+        const int P = 64 / d->Cin;
+        const int KWc = (d->KW + P - 1) / P;
+        PE_REQUIRE(d->KH * KWc <= kMaxTaps, PE_E_UNSUPPORTED,
+                   "pe_conv2d_fwd_bf16: filter %dx%d not supported", d->KH, d->KW);
+        p.Cin = 64;
+        p.cshift = d->Cin == 8 ? 3 : (d->Cin == 16 ? 4 : 5);
+        p.cmask = d->Cin - 1;
+        p.T = d->KH * KWc;
+        for (int kh = 0; kh < d->KH; ++kh)
+            for (int c = 0; c < KWc; ++c) {
+                p.tap_dy[kh * KWc + c] = (int16_t)(kh - d->pad);
+                p.tap_dx[kh * KWc + c] = (int16_t)(c * P - d->pad);
+            }
+    } else {
+        p.T = d->KH * d->KW;
+        for (int kh = 0; kh < d->KH; ++kh)
+            for (int kw = 0; kw < d->KW; ++kw) {
+                p.tap_dy[kh * d->KW + kw] = (int16_t)(kh - d->pad);
+                p.tap_dx[kh * d->KW + kw] = (int16_t)(kw - d->pad);
+            }
+    }
     p.OH = Ho;
     p.OW = Wo;
     p.ldc = d->Cout;

@@ -1,0 +1,292 @@
+"""HRNet-W32-style multi-branch pose network (inference) on the HIP kernels, for the
+high-resolution configuration: 384x288 images, 96x72 heat maps.
+
+The reference's own network is MobileNetV2 (nets/mobilenet_v2.py, model/mobilenet_pose.py;
+PoseEstimation.pyproj:31-32, absent); this backbone is not in it.  Architecture = the public
+HRNet-W32 pose definition: two 3x3/2 stem convs to 64 channels, four bottlenecks (256 channels),
+then three stages of parallel branches at strides 4/8/16/32 with widths 32/64/128/256
+(1, 4 and 3 exchange modules; four basic blocks per branch per module), and a 1x1 head on the
+stride-4 branch.  Every conv is followed by BN; ReLU follows except before a residual or
+fusion sum, which applies it after the sum.
+
+How it maps onto the kernels:
+  * every conv + folded BN (+ residual) (+ ReLU) is one pe_conv2d_fwd_bf16 launch; the
+    32-channel branch uses the narrow-input weight packing (two pixels per 64-element K run)
+    instead of padding the branch to 64 channels;
+  * a fusion output i sums, in this order: its own branch, the stride-2 3x3 chains from the
+    higher-resolution branches (each chain's last conv takes the running sum as its residual),
+    then the 1x1-projected lower-resolution branches, which one pe_fuse_upsample_add_bf16
+    launch upsamples (nearest), adds and rectifies.
+Activations are NHWC bf16; BN is folded into per-channel float32 scale and shift.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional
+
+import torch
+
+from . import nn as pnn
+from . import ops
+
+BF16 = torch.bfloat16
+BN_EPS = 1e-5
+
+
+@dataclass
+class Unit:
+    """conv k x k (pad k//2) + BN (+ ReLU)."""
+    name: str
+    cin: int
+    cout: int
+    k: int
+    stride: int = 1
+    relu: bool = True
+
+
+@dataclass
+class Bottleneck:
+    c1: Unit
+    c2: Unit
+    c3: Unit
+    down: Optional[Unit]
+
+
+@dataclass
+class BasicBlock:
+    c1: Unit
+    c2: Unit
+
+
+@dataclass
+class Module:
+    branches: List[List[BasicBlock]]
+    # fuse[i][j]: None when i == j, [1x1 unit] when j > i (then upsampled by 2^(j-i)),
+    # a chain of (i - j) stride-2 3x3 units when j < i
+    fuse: List[List[Optional[List[Unit]]]] = field(default_factory=list)
+
+
+@dataclass
+class HRNetSpec:
+    stem: List[Unit]
+    layer1: List[Bottleneck]
+    transitions: List[List[Optional[Unit]]]   # per stage, per branch: None = pass through
+    stages: List[List[Module]]
+    widths: List[int]
+    num_joints: int
+
+
+def hrnet_specs(num_joints: int = 17, width: int = 32, modules=(1, 4, 3), blocks: int = 4,
+                layer1_blocks: int = 4) -> HRNetSpec:
+    widths = [width, 2 * width, 4 * width, 8 * width]
+    stem = [Unit("stem.conv1", 3, 64, 3, 2), Unit("stem.conv2", 64, 64, 3, 2)]
+    layer1 = []
+    cin = 64
+    for i in range(layer1_blocks):
+        n = f"layer1.{i}"
+        layer1.append(Bottleneck(Unit(n + ".conv1", cin, 64, 1), Unit(n + ".conv2", 64, 64, 3),
+                                 Unit(n + ".conv3", 64, 256, 1, relu=False),
+                                 Unit(n + ".down", cin, 256, 1, relu=False) if cin != 256 else None))
+        cin = 256
+    transitions, stages = [], []
+    prev = [256]
+    for si, nmod in enumerate(modules):
+        nb = si + 2
+        cur = widths[:nb]
+        tr: List[Optional[Unit]] = []
+        for i in range(nb):
+            if i < len(prev):
+                tr.append(Unit(f"transition{si + 1}.{i}", prev[i], cur[i], 3)
+                          if prev[i] != cur[i] else None)
+            else:
+                tr.append(Unit(f"transition{si + 1}.{i}", prev[-1], cur[i], 3, 2))
+        transitions.append(tr)
+        mods = []
+        for m in range(nmod):
+            last = si == len(modules) - 1 and m == nmod - 1   # only the stride-4 output is used
+            name = f"stage{si + 2}.{m}"
+            br = [[BasicBlock(Unit(f"{name}.branch{i}.{k}.conv1", cur[i], cur[i], 3),
+                              Unit(f"{name}.branch{i}.{k}.conv2", cur[i], cur[i], 3, relu=False))
+                   for k in range(blocks)] for i in range(nb)]
+            fuse: List[List[Optional[List[Unit]]]] = []
+            for i in range(1 if last else nb):
+                row: List[Optional[List[Unit]]] = []
+                for j in range(nb):
+                    if j == i:
+                        row.append(None)
+                    elif j > i:
+                        row.append([Unit(f"{name}.fuse{i}.{j}", cur[j], cur[i], 1, relu=False)])
+                    else:
+                        chain = []
+                        for k in range(i - j):
+                            end = k == i - j - 1
+                            chain.append(Unit(f"{name}.fuse{i}.{j}.{k}", cur[j],
+                                              cur[i] if end else cur[j], 3, 2, relu=not end))
+                        row.append(chain)
+                fuse.append(row)
+            mods.append(Module(br, fuse))
+        stages.append(mods)
+        prev = cur
+    return HRNetSpec(stem, layer1, transitions, stages, widths, num_joints)
+
+
+def all_units(spec: HRNetSpec) -> List[Unit]:
+    out = list(spec.stem)
+    for b in spec.layer1:
+        out += [b.c1, b.c2, b.c3] + ([b.down] if b.down else [])
+    for tr, mods in zip(spec.transitions, spec.stages):
+        out += [t for t in tr if t is not None]
+        for m in mods:
+            for br in m.branches:
+                for blk in br:
+                    out += [blk.c1, blk.c2]
+            for row in m.fuse:
+                for chain in row:
+                    out += chain or []
+    return out
+
+
+def forward_macs(spec: HRNetSpec, H: int = 384, W: int = 288) -> int:
+    """Multiply-accumulates of one forward, from the layer list (true channel counts)."""
+    res = {}
+
+    def run(u: Unit, h: int, w: int):
+        ho, wo = (h - 1) // u.stride + 1, (w - 1) // u.stride + 1
+        res["macs"] = res.get("macs", 0) + ho * wo * u.k * u.k * u.cin * u.cout
+        return ho, wo
+
+    h, w = H, W
+    for u in spec.stem:
+        h, w = run(u, h, w)
+    for b in spec.layer1:
+        for u in (b.c1, b.c2, b.c3) + ((b.down,) if b.down else ()):
+            run(u, h, w)
+    sizes = [(h, w)]
+    for tr, mods in zip(spec.transitions, spec.stages):
+        new = []
+        for i, t in enumerate(tr):
+            src = sizes[i] if i < len(sizes) else sizes[-1]
+            new.append(run(t, *src) if t is not None else src)
+        sizes = new
+        for m in mods:
+            for i, br in enumerate(m.branches):
+                for blk in br:
+                    run(blk.c1, *sizes[i])
+                    run(blk.c2, *sizes[i])
+            for row in m.fuse:
+                for j, chain in enumerate(row):
+                    s = sizes[j]
+                    for u in chain or []:
+                        s = run(u, *s)
+    res["macs"] += sizes[0][0] * sizes[0][1] * spec.widths[0] * spec.num_joints
+    return res["macs"]
+
+
+def init_state(spec: HRNetSpec, seed: int = 3) -> Dict[str, torch.Tensor]:
+    """Random-init state dict in framework layouts (CPU float32): He-normal convs (fan-out),
+    BN gamma 1 / beta 0 / running (0, 1), head N(0, 0.001) with zero bias."""
+    g = torch.Generator().manual_seed(seed)
+    st: Dict[str, torch.Tensor] = {}
+    for u in all_units(spec):
+        st[u.name + ".weight"] = torch.randn((u.cout, u.cin, u.k, u.k), generator=g) \
+            * (2.0 / (u.cout * u.k * u.k)) ** 0.5
+        st[u.name + ".bn.gamma"] = torch.ones(u.cout)
+        st[u.name + ".bn.beta"] = torch.zeros(u.cout)
+        st[u.name + ".bn.mean"] = torch.zeros(u.cout)
+        st[u.name + ".bn.var"] = torch.ones(u.cout)
+    st["final.weight"] = torch.randn((spec.num_joints, spec.widths[0], 1, 1), generator=g) * 0.001
+    st["final.bias"] = torch.zeros(spec.num_joints)
+    return st
+
+
+class PoseHRNet:
+    """HRNet-W32-style pose network on one GPU, inference only."""
+
+    def __init__(self, device, num_joints: int = 17, width: int = 32, modules=(1, 4, 3),
+                 blocks: int = 4, layer1_blocks: int = 4):
+        self.device = torch.device(device)
+        self.spec = hrnet_specs(num_joints, width, modules, blocks, layer1_blocks)
+        self.p: Dict[str, torch.Tensor] = {}
+
+    # ------------------------------------------------------------------ parameters
+    def _pack(self, w: torch.Tensor) -> torch.Tensor:
+        cin = w.shape[1]
+        if cin in (8, 16, 32):
+            return pnn.pack_conv_weight_narrow(w)
+        if cin % 64 != 0:
+            raise ValueError(f"input channels {cin}: need 8, 16, 32 or a multiple of 64")
+        return pnn.pack_conv_weight(w)
+
+    def load_state(self, st: Dict[str, torch.Tensor]) -> None:
+        self.p.clear()
+        for u in all_units(self.spec):
+            w = st[u.name + ".weight"]
+            if u.name == "stem.conv1":
+                pw = pnn.pack_stem3x3_weight(w)
+            else:
+                pw = self._pack(w)
+            sc = st[u.name + ".bn.gamma"] / torch.sqrt(st[u.name + ".bn.var"] + BN_EPS)
+            sh = st[u.name + ".bn.beta"] - st[u.name + ".bn.mean"] * sc
+            self.p[u.name + ".weight"] = pw.to(self.device)
+            self.p[u.name + ".scale"] = sc.float().contiguous().to(self.device)
+            self.p[u.name + ".shift"] = sh.float().contiguous().to(self.device)
+        self.p["final.weight"] = self._pack(st["final.weight"]).to(self.device)
+        self.p["final.bias"] = st["final.bias"].float().to(self.device)
+
+    # ------------------------------------------------------------------ inference
+    def _unit(self, u: Unit, x: torch.Tensor, residual=None, relu=None) -> torch.Tensor:
+        p = self.p
+        return pnn.conv2d(x, p[u.name + ".weight"], p[u.name + ".scale"], p[u.name + ".shift"],
+                          residual, u.stride, u.k // 2, u.relu if relu is None else relu, kw=u.k)
+
+    def _module(self, m: Module, xs: List[torch.Tensor]) -> List[torch.Tensor]:
+        ys = []
+        for x, br in zip(xs, m.branches):
+            for blk in br:
+                x = self._unit(blk.c2, self._unit(blk.c1, x), residual=x, relu=True)
+            ys.append(x)
+        outs = []
+        for i, row in enumerate(m.fuse):
+            lows = [(j, row[j]) for j in range(len(row)) if j > i]
+            s = ys[i]
+            for j in range(i):
+                t = ys[j]
+                chain = row[j]
+                for u in chain[:-1]:
+                    t = self._unit(u, t)
+                # the last conv of the chain adds the running sum; it also rectifies when
+                # nothing else follows
+                s = self._unit(chain[-1], t, residual=s, relu=(j == i - 1 and not lows))
+            if lows:
+                proj = [self._unit(chain[0], ys[j]) for j, chain in lows]
+                s = pnn.fuse_upsample_add(s, proj, [j - i for j, _ in lows], relu=True)
+            outs.append(s)
+        return outs
+
+    def forward_features(self, x_s2d: torch.Tensor) -> torch.Tensor:
+        sp, p = self.spec, self.p
+        u = sp.stem[0]
+        x = pnn.stem3x3s2(x_s2d, p[u.name + ".weight"], p[u.name + ".scale"],
+                          p[u.name + ".shift"], relu=1)
+        x = self._unit(sp.stem[1], x)
+        for b in sp.layer1:
+            idn = self._unit(b.down, x) if b.down else x
+            x = self._unit(b.c3, self._unit(b.c2, self._unit(b.c1, x)), residual=idn, relu=True)
+        xs = [x]
+        for tr, mods in zip(sp.transitions, sp.stages):
+            xs = [(xs[i] if t is None else self._unit(t, xs[i])) if i < len(xs)
+                  else self._unit(t, xs[-1]) for i, t in enumerate(tr)]
+            for m in mods:
+                xs = self._module(m, xs)
+        return xs[0]
+
+    def predict(self, images_u8: torch.Tensor) -> torch.Tensor:
+        """uint8 [B,H,W,3] -> heat maps float32 [B,K,H/4,W/4]."""
+        if not self.p:
+            raise RuntimeError("load_state() has not been called")
+        f = self.forward_features(pnn.preprocess_u8(images_u8))
+        return pnn.conv2d(f, self.p["final.weight"], None, self.p["final.bias"],
+                          out_f32_nchw=True, kw=1)
+
+    def decode(self, heatmaps: torch.Tensor):
+        return ops.decode(heatmaps)

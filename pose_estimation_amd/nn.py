@@ -25,6 +25,19 @@ def pack_conv_weight(w_oihw: torch.Tensor) -> torch.Tensor:
     return w_oihw.permute(0, 2, 3, 1).contiguous().to(BF16)
 
 
+def pack_conv_weight_narrow(w_oihw: torch.Tensor) -> torch.Tensor:
+    """[Cout,Cin,KH,KW] with Cin of 8, 16 or 32 -> bf16 [Cout,KH,ceil(KW/P),P*Cin], P = 64/Cin:
+    run c of a filter row holds taps kw = c*P .. c*P+P-1 pixel by pixel, zero past the filter."""
+    cout, cin, kh, kw = w_oihw.shape
+    if cin not in (8, 16, 32):
+        raise ValueError("narrow packing is for 8, 16 or 32 input channels")
+    P = 64 // cin
+    kwc = (kw + P - 1) // P
+    out = torch.zeros(cout, kh, kwc * P, cin, dtype=w_oihw.dtype, device=w_oihw.device)
+    out[:, :, :kw, :] = w_oihw.permute(0, 2, 3, 1)
+    return out.reshape(cout, kh, kwc, P * cin).contiguous().to(BF16)
+
+
 def deconv_phase_taps(py: int, a: int):
     """Kernel index and input offset of tap `a` (0/1) of output parity `py` for a 4x4,
     stride-2, pad-1 transposed conv: out[2Y+py] += in[Y+d] * w[k]."""
@@ -80,13 +93,22 @@ def _check_act(x: torch.Tensor, name: str = "x"):
 def conv2d(x: torch.Tensor, w: torch.Tensor, scale: Optional[torch.Tensor] = None,
            shift: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
            stride: int = 1, pad: int = 0, relu: bool = False, out_f32_nchw: bool = False,
-           out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """y = relu?( conv(x, w) * scale + shift + residual ).  x [B,H,W,Cin], w [Cout,KH,KW,Cin]."""
+           out: Optional[torch.Tensor] = None, kw: Optional[int] = None) -> torch.Tensor:
+    """y = relu?( conv(x, w) * scale + shift + residual ).  x [B,H,W,Cin], w [Cout,KH,KW,Cin].
+    With 8, 16 or 32 input channels w is the pack_conv_weight_narrow layout and `kw` gives the
+    filter width."""
     _check_act(x)
     _need_gpu(w, scale, shift, residual, out)
     B, H, W, Cin = x.shape
     Cout, KH, KW, Cin2 = w.shape
-    if Cin2 != Cin or w.dtype != BF16 or not w.is_contiguous():
+    if Cin in (8, 16, 32):
+        P = 64 // Cin
+        if kw is None or Cin2 != 64 or KW != (kw + P - 1) // P:
+            raise ValueError("narrow conv: w must be [Cout,KH,ceil(kw/P),64] and kw given")
+        KW = kw
+    elif Cin2 != Cin:
+        raise ValueError("w must be contiguous bfloat16 [Cout,KH,KW,Cin]")
+    if w.dtype != BF16 or not w.is_contiguous():
         raise ValueError("w must be contiguous bfloat16 [Cout,KH,KW,Cin]")
     Ho = (H + 2 * pad - KH) // stride + 1
     Wo = (W + 2 * pad - KW) // stride + 1
@@ -101,6 +123,36 @@ def conv2d(x: torch.Tensor, w: torch.Tensor, scale: Optional[torch.Tensor] = Non
     with torch.cuda.device(x.device):
         check(lib().pe_conv2d_fwd_bf16(ctypes.addressof(d), x.data_ptr(), w.data_ptr(), _ptr(scale),
                                        _ptr(shift), _ptr(residual), out.data_ptr(), _stream(x)))
+    return out
+
+
+def fuse_upsample_add(base: Optional[torch.Tensor], lows, log2_factors, relu: bool = True,
+                      out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """relu?( base + sum_i nearest_upsample(lows[i], 2**log2_factors[i]) ), NHWC bf16, summed in
+    float32.  base may be None when there is at least one low-resolution map."""
+    lows = list(lows)
+    if base is None and not lows:
+        raise ValueError("nothing to add")
+    if base is not None:
+        _check_act(base, "base")
+        B, H, W, C = base.shape
+    else:
+        _check_act(lows[0], "lows[0]")
+        B, h, w, C = lows[0].shape
+        H, W = h << log2_factors[0], w << log2_factors[0]
+    for t, f in zip(lows, log2_factors):
+        _check_act(t, "low")
+        if tuple(t.shape) != (B, H >> f, W >> f, C):
+            raise ValueError(f"low-resolution map {tuple(t.shape)} does not match {(B, H >> f, W >> f, C)}")
+    if out is None:
+        out = torch.empty((B, H, W, C), dtype=BF16, device=lows[0].device if base is None else base.device)
+    n = len(lows)
+    ptrs = (ctypes.c_void_p * max(n, 1))(*[t.data_ptr() for t in lows])
+    facs = (ctypes.c_int32 * max(n, 1))(*[int(f) for f in log2_factors[:n]])
+    with torch.cuda.device(out.device):
+        check(lib().pe_fuse_upsample_add_bf16(_ptr(base), n, ctypes.addressof(ptrs),
+                                              ctypes.addressof(facs), B, H, W, C, int(relu),
+                                              out.data_ptr(), _stream(out)))
     return out
 
 
