@@ -130,12 +130,14 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const uint16_t* __restri
     }
 }
 
-// Second reduction stage.  A workgroup folds the per-block partials of 8 channels: thread
-// (slice, ch) adds blocks slice, slice+32, ... in order, then the 32 slices are added in order
-// by the threads of slice 0, which return their channel (every other thread returns -1).
-// Launch with C/8 workgroups of 256 threads.
-constexpr int kFoldCh = 8;
-constexpr int kFoldSlices = 32;
+// Second reduction stage.  A workgroup folds the per-block partials of 4 channels: thread
+// (slice, ch) adds blocks slice, slice+64, ... eight at a time (eight independent loads in
+// flight: the stage is latency-bound), then the 64 slices are added in order by the threads of
+// slice 0, which return their channel (every other thread returns -1).  The order of additions
+// is fixed by (nblk, C) alone.  Launch with C/4 workgroups of 256 threads.
+constexpr int kFoldCh = 4;
+constexpr int kFoldSlices = 64;
+constexpr int kFoldUnroll = 8;
 __device__ __forceinline__ int fold_partials(const float* __restrict__ partial, int nblk, int C,
                                              float& s1, float& s2) {
     __shared__ float red[2][kFoldSlices][kFoldCh + 1];
@@ -144,9 +146,19 @@ __device__ __forceinline__ int fold_partials(const float* __restrict__ partial, 
     const int c = blockIdx.x * kFoldCh + ch;
     float a1 = 0.0f, a2 = 0.0f;
     if (c < C) {
-        for (int b = slice; b < nblk; b += kFoldSlices) {
-            a1 += partial[(long)b * 2 * C + c];
-            a2 += partial[(long)b * 2 * C + C + c];
+        for (int b0 = slice; b0 < nblk; b0 += kFoldSlices * kFoldUnroll) {
+            float v1[kFoldUnroll], v2[kFoldUnroll];
+#pragma unroll
+            for (int u = 0; u < kFoldUnroll; ++u) {
+                const int b = b0 + u * kFoldSlices;
+                const bool ok = b < nblk;
+                const long off = (long)(ok ? b : b0) * 2 * C + c;
+                const float x1 = partial[off], x2 = partial[off + C];
+                v1[u] = ok ? x1 : 0.0f;
+                v2[u] = ok ? x2 : 0.0f;
+            }
+            a1 += ((v1[0] + v1[1]) + (v1[2] + v1[3])) + ((v1[4] + v1[5]) + (v1[6] + v1[7]));
+            a2 += ((v2[0] + v2[1]) + (v2[2] + v2[3])) + ((v2[4] + v2[5]) + (v2[6] + v2[7]));
         }
     }
     red[0][slice][ch] = a1;
