@@ -11,6 +11,7 @@ namespace pe {
 // dW slab in the workspace and an ordered reduction folds them (bit-stable, no float atomics).
 // Two workgroups per CU measured best on the training step (256: 14.2 ms, 512: 13.2, 1024: 13.3).
 constexpr long kWgradTargetBlocks = 512;
+constexpr long kWgradMaxBlocks = 2048;   // upper bound the workspace is sized for
 
 struct WgradParams {
     const uint16_t* x;   // forward input, NHWC bf16, Cx channels per pixel

@@ -20,6 +20,8 @@
 // The pixel range is split across gridDim.y.  Each split stores its partial tile to a slab of
 // the workspace (LDS-staged so a wave writes 256 contiguous bytes) and wgrad_reduce_kernel adds
 // the slabs to dW in a fixed order: no float atomics, so a step repeats bit for bit.
+#include <stdlib.h>
+
 #include "pe_common.h"
 #include "pe_wgrad.h"
 
@@ -266,7 +268,10 @@ int32_t wgrad_launch(WgradParams& p, void* workspace, size_t workspace_bytes, hi
     const long ktot = (long)p.T * p.Cin;
     const long P = (long)p.Nw * ktot;
     const long tiles = ((p.N + 127) / 128) * ((ktot + 127) / 128);
-    long splits = (kWgradTargetBlocks + tiles - 1) / tiles;
+    static const char* tune = getenv("PE_WGRAD_BLOCKS");  // tuning aid, at most kWgradMaxBlocks
+    long target = tune ? atol(tune) : kWgradTargetBlocks;
+    if (target < 1 || target > kWgradMaxBlocks) target = kWgradTargetBlocks;
+    long splits = (target + tiles - 1) / tiles;
     const long max_splits = (M + 255) / 256;
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
@@ -309,7 +314,7 @@ int32_t wgrad_launch(WgradParams& p, void* workspace, size_t workspace_bytes, hi
 
 size_t wgrad_workspace_bytes(long P) {
     // splits * P <= (target/tiles + 1) * P with tiles >= P / 16384
-    const size_t by_target = (size_t)(kWgradTargetBlocks + 1) * 16384 * sizeof(float);
+    const size_t by_target = (size_t)(kWgradMaxBlocks + 1) * 16384 * sizeof(float);
     const size_t two = 2 * (size_t)P * sizeof(float);
     return (by_target > two ? by_target : two) + (size_t)P * sizeof(float);
 }

@@ -9,6 +9,7 @@ parallelism (test.ipynb:12): local batch statistics, summed gradients averaged o
 """
 from __future__ import annotations
 
+from contextlib import contextmanager
 from typing import Dict, List, Optional
 
 import torch
@@ -54,6 +55,10 @@ class TrainablePoseResNet(PoseResNet):
         self.layer_starts: List[int] = [self.offsets[c.name + ".weight"][0] for c in self.convs]
         self.bucketer: Optional[GradBucketer] = None
         self.saved: dict = {}
+        # Weight gradients run on their own stream: they depend only on a layer's input and its
+        # output gradient, nothing downstream reads them before the optimizer, and at batch 64
+        # many backward kernels leave CUs idle, so they fill in beside the backward-data chain.
+        self.wgrad_stream: Optional[torch.cuda.Stream] = torch.cuda.Stream(device=dev)
 
     # ------------------------------------------------------------------ set-up
     def load_state(self, state) -> None:
@@ -146,24 +151,30 @@ class TrainablePoseResNet(PoseResNet):
         hw_in = tuple(x.shape[1:3])
         hw_mid = tuple(s["a1"].shape[1:3])
         dz3, g3 = self._bn_bwd(b.c3, dout, s["out"], s["z3"], want_masked=True)
-        pnn.conv2d_bwd_weight(s["a2"], dz3, self._g(b.c3.name + ".weight"), 1, 1, 0)
-        da2 = pnn.conv2d_bwd_data(dz3, self.wt[b.c3.name], tuple(s["a2"].shape[1:3]), 1, 1, 0)
         if b.down:
-            # the arena holds `down` after conv3, so it is finished before conv3 is marked
             dzd, _ = self._bn_bwd(b.down, g3, None, s["zd"])
-            pnn.conv2d_bwd_weight(x, dzd, self._g(b.down.name + ".weight"), 1, b.down.stride, 0)
-            self._done(b.down)
+            with self._beside(s["a2"], dz3, x, dzd):
+                pnn.conv2d_bwd_weight(s["a2"], dz3, self._g(b.c3.name + ".weight"), 1, 1, 0)
+                pnn.conv2d_bwd_weight(x, dzd, self._g(b.down.name + ".weight"), 1, b.down.stride, 0)
+                # the arena holds `down` after conv3, so it is finished before conv3 is marked
+                self._done(b.down)
+                self._done(b.c3)
             res = pnn.conv2d_bwd_data(dzd, self.wt[b.down.name], hw_in, 1, b.down.stride, 0)
         else:
+            with self._beside(s["a2"], dz3):
+                pnn.conv2d_bwd_weight(s["a2"], dz3, self._g(b.c3.name + ".weight"), 1, 1, 0)
+                self._done(b.c3)
             res = g3
-        self._done(b.c3)
+        da2 = pnn.conv2d_bwd_data(dz3, self.wt[b.c3.name], tuple(s["a2"].shape[1:3]), 1, 1, 0)
         dz2, _ = self._bn_bwd(b.c2, da2, s["a2"], s["z2"])
-        pnn.conv2d_bwd_weight(s["a1"], dz2, self._g(b.c2.name + ".weight"), 3, b.c2.stride, 1)
-        self._done(b.c2)
+        with self._beside(s["a1"], dz2):
+            pnn.conv2d_bwd_weight(s["a1"], dz2, self._g(b.c2.name + ".weight"), 3, b.c2.stride, 1)
+            self._done(b.c2)
         da1 = pnn.conv2d_bwd_data(dz2, self.wt[b.c2.name], hw_mid, 3, b.c2.stride, 1)
         dz1, _ = self._bn_bwd(b.c1, da1, s["a1"], s["z1"])
-        pnn.conv2d_bwd_weight(x, dz1, self._g(b.c1.name + ".weight"), 1, 1, 0)
-        self._done(b.c1)
+        with self._beside(x, dz1):
+            pnn.conv2d_bwd_weight(x, dz1, self._g(b.c1.name + ".weight"), 1, 1, 0)
+            self._done(b.c1)
         return pnn.conv2d_bwd_data(dz1, self.wt[b.c1.name], hw_in, 1, 1, 0, residual=res)
 
     def deconv_forward(self, d, x: torch.Tensor) -> dict:
@@ -173,8 +184,9 @@ class TrainablePoseResNet(PoseResNet):
 
     def deconv_backward(self, d, s: dict, da: torch.Tensor) -> torch.Tensor:
         dz, _ = self._bn_bwd(d, da, s["a"], s["z"])
-        pnn.deconv4x4s2_bwd_weight(s["x"], dz, self._g(d.name + ".weight"))
-        self._done(d)
+        with self._beside(s["x"], dz):
+            pnn.deconv4x4s2_bwd_weight(s["x"], dz, self._g(d.name + ".weight"))
+            self._done(d)
         return pnn.deconv4x4s2_bwd_data(dz, self.wt[d.name])
 
     def forward_train(self, images_u8: Optional[torch.Tensor],
@@ -213,6 +225,21 @@ class TrainablePoseResNet(PoseResNet):
         if self.bucketer is not None:
             self.bucketer.layer_done(self.offsets[c.name + ".weight"][0])
 
+    @contextmanager
+    def _beside(self, *tensors: torch.Tensor):
+        """Launches inside run on the weight-gradient stream, after everything queued on the
+        current stream so far.  `tensors` are what those launches read: the caching allocator is
+        told not to hand their memory out again before the side stream is done with it."""
+        side = self.wgrad_stream
+        if side is None:
+            yield
+            return
+        side.wait_stream(torch.cuda.current_stream(self.device))
+        for t in tensors:
+            t.record_stream(side)
+        with torch.cuda.stream(side):
+            yield
+
     def backward(self, grad_hm: torch.Tensor) -> None:
         """grad_hm: float32 [B,K,H,W] = dLoss/dHeatmaps.  Fills self.grads (pre-zeroed here)."""
         stem, blocks, deconvs, final = self.specs
@@ -220,9 +247,10 @@ class TrainablePoseResNet(PoseResNet):
         self.grads.zero_()
         # final 1x1 conv + bias
         dyp = pnn.final_grad_prepare(grad_hm, FINAL_KPAD, self._g(final.name + ".bias"))
-        pnn.conv2d_bwd_weight(sv["feat"], dyp, self._g(final.name + ".weight"), 1, 1, 0,
-                              cout=final.cout)
-        self._done(final)
+        with self._beside(sv["feat"], dyp):
+            pnn.conv2d_bwd_weight(sv["feat"], dyp, self._g(final.name + ".weight"), 1, 1, 0,
+                                  cout=final.cout)
+            self._done(final)
         H, W = sv["feat"].shape[1:3]
         dx = pnn.conv2d_bwd_data(dyp, self.wt[final.name], (H, W), 1, 1, 0)
         # deconv head
@@ -235,9 +263,12 @@ class TrainablePoseResNet(PoseResNet):
         da0 = pnn.maxpool3x3s2_bwd(sv["pool_idx"], dx)
         dz0, _ = self._bn_bwd(stem, da0, sv["a0"], sv["z0"])
         gw = self._g(stem.name + ".weight")
-        pnn.stem7x7s2_bwd_weight(sv["xs"], dz0, gw)
-        pnn.mul_(gw, self.stem_mask)
-        self._done(stem)
+        with self._beside(sv["xs"], dz0):
+            pnn.stem7x7s2_bwd_weight(sv["xs"], dz0, gw)
+            pnn.mul_(gw, self.stem_mask)
+            self._done(stem)
+        if self.wgrad_stream is not None:   # the optimizer reads every gradient
+            torch.cuda.current_stream(self.device).wait_stream(self.wgrad_stream)
 
     # ------------------------------------------------------------------ one optimisation step
     def train_step(self, images_u8: torch.Tensor, joints: torch.Tensor,
