@@ -17,7 +17,7 @@ import torch
 
 from ._ffi import check, lib
 from .nn import BF16, IMAGENET_MEAN, IMAGENET_STD
-from .ops import _need_gpu, _stream
+from .ops import _need_gpu, _stream, on_device
 
 # COCO order: nose, eyes, ears, shoulders, elbows, wrists, hips, knees, ankles
 COCO_FLIP_PERM = (0, 2, 1, 4, 3, 6, 5, 8, 7, 10, 9, 12, 11, 14, 13, 16, 15)
@@ -68,7 +68,7 @@ def augment_u8(img: torch.Tensor, params: torch.Tensor, out_hw: Tuple[int, int],
         out = torch.empty((B, H // 2, W // 2, 16), dtype=BF16, device=img.device)
     m = (ctypes.c_float * 3)(*mean)
     s = (ctypes.c_float * 3)(*std)
-    with torch.cuda.device(img.device):
+    with on_device(img):
         check(lib().pe_augment_u8_s2d_bf16(img.data_ptr(), B, Hs, Ws, params.data_ptr(), H, W,
                                            ctypes.addressof(m), ctypes.addressof(s),
                                            out.data_ptr(), _stream(img)))
@@ -91,7 +91,7 @@ def transform_joints(joints: torch.Tensor, params: torch.Tensor, out_w: int,
         if len(flip_perm) != K:
             raise ValueError("flip_perm must name one source joint per joint")
         perm = (ctypes.c_int32 * K)(*flip_perm)
-    with torch.cuda.device(joints.device):
+    with on_device(joints):
         check(lib().pe_transform_joints_f32(joints.data_ptr(), B, K, params.data_ptr(), int(out_w),
                                             ctypes.addressof(perm) if perm is not None else None,
                                             out.data_ptr(), _stream(joints)))

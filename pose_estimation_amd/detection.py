@@ -16,7 +16,7 @@ import numpy as np
 import torch
 
 from ._ffi import check, lib
-from .ops import _need_gpu, _stream
+from .ops import _need_gpu, _stream, on_device
 
 DEFAULT_LEVELS = ((20, 20), (10, 10))
 DEFAULT_SCALES = (0.35, 0.75)

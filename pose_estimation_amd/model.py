@@ -167,6 +167,7 @@ class PoseResNet:
                 self.offsets[c.name + nm] = (off, (c.cout,))
                 off += _align8(c.cout)
         self.n_params = off
+        self._views: Dict[tuple, torch.Tensor] = {}
         self.master = torch.zeros(off, dtype=torch.float32, device=self.device)
         self.work = torch.zeros(off, dtype=BF16, device=self.device)
         self.bn_mean = {c.name: torch.zeros(c.cout, device=self.device) for c in self.convs if c.bn}
@@ -176,11 +177,18 @@ class PoseResNet:
 
     # ------------------------------------------------------------------ parameters
     def view(self, arena: torch.Tensor, name: str) -> torch.Tensor:
-        off, shp = self.offsets[name]
-        n = 1
-        for s in shp:
-            n *= s
-        return arena[off:off + n].view(shp)
+        """The named parameter inside an arena laid out like the master.  Views are cached per
+        (arena storage, dtype): a training step asks for several hundred of them."""
+        key = (arena.data_ptr(), arena.dtype, name)
+        v = self._views.get(key)
+        if v is None:
+            off, shp = self.offsets[name]
+            n = 1
+            for s in shp:
+                n *= s
+            v = arena[off:off + n].view(shp)
+            self._views[key] = v
+        return v
 
     def load_state(self, state: Dict[str, torch.Tensor]) -> None:
         """Copy a framework-layout state dict into the arenas (packing every weight)."""

@@ -14,7 +14,7 @@ import numpy as np
 import torch
 
 from ._ffi import ConvDesc, check, lib
-from .ops import _need_gpu, _ptr, _stream
+from .ops import _need_gpu, _ptr, _stream, on_device
 
 BF16 = torch.bfloat16
 
@@ -120,7 +120,7 @@ def conv2d(x: torch.Tensor, w: torch.Tensor, scale: Optional[torch.Tensor] = Non
     if residual is not None and (residual.shape != out.shape or residual.dtype != BF16):
         raise ValueError("residual must match the output")
     d = ConvDesc(B, H, W, Cin, Cout, KH, KW, stride, pad, int(relu), int(out_f32_nchw))
-    with torch.cuda.device(x.device):
+    with on_device(x):
         check(lib().pe_conv2d_fwd_bf16(ctypes.addressof(d), x.data_ptr(), w.data_ptr(), _ptr(scale),
                                        _ptr(shift), _ptr(residual), out.data_ptr(), _stream(x)))
     return out
@@ -149,7 +149,7 @@ def fuse_upsample_add(base: Optional[torch.Tensor], lows, log2_factors, relu: bo
     n = len(lows)
     ptrs = (ctypes.c_void_p * max(n, 1))(*[t.data_ptr() for t in lows])
     facs = (ctypes.c_int32 * max(n, 1))(*[int(f) for f in log2_factors[:n]])
-    with torch.cuda.device(out.device):
+    with on_device(out):
         check(lib().pe_fuse_upsample_add_bf16(_ptr(base), n, ctypes.addressof(ptrs),
                                               ctypes.addressof(facs), B, H, W, C, int(relu),
                                               out.data_ptr(), _stream(out)))
@@ -166,7 +166,7 @@ def deconv4x4s2(x: torch.Tensor, w_phases: torch.Tensor, scale=None, shift=None,
         raise ValueError("w_phases must be bfloat16 [4,Cout,4,Cin]")
     if out is None:
         out = torch.empty((B, 2 * H, 2 * W, Cout), dtype=BF16, device=x.device)
-    with torch.cuda.device(x.device):
+    with on_device(x):
         check(lib().pe_deconv4x4s2_fwd_bf16(B, H, W, Cin, Cout, int(relu), x.data_ptr(),
                                             w_phases.data_ptr(), _ptr(scale), _ptr(shift),
                                             out.data_ptr(), _stream(x)))
@@ -183,7 +183,7 @@ def stem7x7s2(x_s2d: torch.Tensor, w: torch.Tensor, scale=None, shift=None, relu
         raise ValueError("stem expects x_s2d [...,16] and w bfloat16 [Cout,4,64]")
     if out is None:
         out = torch.empty((B, H2, W2, Cout), dtype=BF16, device=x_s2d.device)
-    with torch.cuda.device(x_s2d.device):
+    with on_device(x_s2d):
         check(lib().pe_stem7x7s2_fwd_bf16(B, H2, W2, Cout, int(relu), x_s2d.data_ptr(),
                                           w.data_ptr(), _ptr(scale), _ptr(shift), out.data_ptr(),
                                           _stream(x_s2d)))
@@ -206,7 +206,7 @@ def conv2d_bnstats(x: torch.Tensor, w: torch.Tensor, ws: torch.Tensor, stride: i
         out = torch.empty((B, Ho, Wo, Cout), dtype=BF16, device=x.device)
     d = ConvDesc(B, H, W, Cin, Cout, KH, KW, stride, pad, 0, 0)
     rows = ctypes.c_int32(0)
-    with torch.cuda.device(x.device):
+    with on_device(x):
         check(lib().pe_conv2d_fwd_bnstats_bf16(ctypes.addressof(d), x.data_ptr(), w.data_ptr(),
                                                out.data_ptr(), ws.data_ptr(), ws.numel(),
                                                ctypes.byref(rows), _stream(x)))
@@ -225,7 +225,7 @@ def deconv4x4s2_bnstats(x: torch.Tensor, w_phases: torch.Tensor, ws: torch.Tenso
     if out is None:
         out = torch.empty((B, 2 * H, 2 * W, Cout), dtype=BF16, device=x.device)
     rows = ctypes.c_int32(0)
-    with torch.cuda.device(x.device):
+    with on_device(x):
         check(lib().pe_deconv4x4s2_fwd_bnstats_bf16(B, H, W, Cin, Cout, x.data_ptr(),
                                                     w_phases.data_ptr(), out.data_ptr(),
                                                     ws.data_ptr(), ws.numel(), ctypes.byref(rows),
@@ -245,7 +245,7 @@ def stem7x7s2_bnstats(x_s2d: torch.Tensor, w: torch.Tensor, ws: torch.Tensor,
     if out is None:
         out = torch.empty((B, H2, W2, Cout), dtype=BF16, device=x_s2d.device)
     rows = ctypes.c_int32(0)
-    with torch.cuda.device(x_s2d.device):
+    with on_device(x_s2d):
         check(lib().pe_stem7x7s2_fwd_bnstats_bf16(B, H2, W2, Cout, x_s2d.data_ptr(), w.data_ptr(),
                                                   out.data_ptr(), ws.data_ptr(), ws.numel(),
                                                   ctypes.byref(rows), _stream(x_s2d)))
@@ -281,7 +281,7 @@ def stem3x3s2(x_s2d: torch.Tensor, w: torch.Tensor, scale=None, shift=None, relu
     Cout = w.shape[0]
     if out is None:
         out = torch.empty((B, H2, W2, Cout), dtype=BF16, device=x_s2d.device)
-    with torch.cuda.device(x_s2d.device):
+    with on_device(x_s2d):
         check(lib().pe_stem3x3s2_fwd_bf16(B, H2, W2, Cout, int(relu), x_s2d.data_ptr(),
                                           w.data_ptr(), _ptr(scale), _ptr(shift), out.data_ptr(),
                                           _stream(x_s2d)))
@@ -298,7 +298,7 @@ def depthwise3x3(x: torch.Tensor, w9c: torch.Tensor, scale=None, shift=None, str
     Ho, Wo = (H - 1) // stride + 1, (W - 1) // stride + 1
     if out is None:
         out = torch.empty((B, Ho, Wo, C), dtype=BF16, device=x.device)
-    with torch.cuda.device(x.device):
+    with on_device(x):
         check(lib().pe_depthwise3x3_fwd_bf16(x.data_ptr(), B, H, W, C, int(stride), int(dilation),
                                              w9c.data_ptr(), _ptr(scale), _ptr(shift), int(relu),
                                              out.data_ptr(), _stream(x)))
@@ -316,7 +316,7 @@ def preprocess_u8(img: torch.Tensor, mean=IMAGENET_MEAN, std=IMAGENET_STD,
         out = torch.empty((B, H // 2, W // 2, 16), dtype=BF16, device=img.device)
     m = (ctypes.c_float * 3)(*mean)
     s = (ctypes.c_float * 3)(*std)
-    with torch.cuda.device(img.device):
+    with on_device(img):
         check(lib().pe_preprocess_u8_s2d_bf16(img.data_ptr(), B, H, W, ctypes.addressof(m),
                                               ctypes.addressof(s), out.data_ptr(), _stream(img)))
     return out
@@ -331,7 +331,7 @@ def maxpool3x3s2(x: torch.Tensor, out: Optional[torch.Tensor] = None, want_index
         out = torch.empty((B, H // 2, W // 2, C), dtype=BF16, device=x.device)
     idx = torch.empty((B, H // 2, W // 2, C), dtype=torch.uint8, device=x.device) if want_index \
         else None
-    with torch.cuda.device(x.device):
+    with on_device(x):
         check(lib().pe_maxpool3x3s2_fwd_bf16(x.data_ptr(), B, H, W, C, out.data_ptr(), _ptr(idx),
                                              _stream(x)))
     return (out, idx) if want_index else out
@@ -346,7 +346,7 @@ def transpose_weights(w: torch.Tensor, out: torch.Tensor, t0: int = 0) -> torch.
     C2, slots, apitch = out.shape
     if C2 != C or w.dtype != BF16 or out.dtype != BF16 or not (w.is_contiguous() and out.is_contiguous()):
         raise ValueError("transpose_weights: w [A,T,C], out [C,slots,apitch], contiguous bf16")
-    with torch.cuda.device(w.device):
+    with on_device(w):
         check(lib().pe_transpose_weights_bf16(w.data_ptr(), A, T, C, out.data_ptr(), slots, apitch,
                                               t0, _stream(w)))
     return out
@@ -387,7 +387,7 @@ class TransposePlan:
                 tiles += T * ((A + 63) // 64) * ((C + 63) // 64)
             self._tiles = tiles
             self._table = torch.from_numpy(rec.view(np.uint8)).to(self.device)
-        with torch.cuda.device(self.device):
+        with on_device(self):
             check(lib().pe_transpose_weights_batched_bf16(
                 self._table.data_ptr(), len(self._jobs), self._tiles,
                 torch.cuda.current_stream(self.device).cuda_stream))
@@ -406,7 +406,7 @@ def conv2d_bwd_data(dy: torch.Tensor, w_t: torch.Tensor, in_hw, k: int, stride: 
     if out is None:
         out = torch.empty((B, H, W, Cin), dtype=BF16, device=dy.device)
     d = ConvDesc(B, H, W, Cin, Cout, k, k, stride, pad, 0, 0)
-    with torch.cuda.device(dy.device):
+    with on_device(dy):
         check(lib().pe_conv2d_bwd_data_bf16(ctypes.addressof(d), dy.data_ptr(), w_t.data_ptr(),
                                             _ptr(residual), out.data_ptr(), _stream(dy)))
     return out
@@ -420,7 +420,7 @@ def deconv4x4s2_bwd_data(dy: torch.Tensor, w_t: torch.Tensor,
     Cin = w_t.shape[0]
     if out is None:
         out = torch.empty((B, H2 // 2, W2 // 2, Cin), dtype=BF16, device=dy.device)
-    with torch.cuda.device(dy.device):
+    with on_device(dy):
         check(lib().pe_deconv4x4s2_bwd_data_bf16(B, H2 // 2, W2 // 2, Cin, Cout, dy.data_ptr(),
                                                  w_t.data_ptr(), out.data_ptr(), _stream(dy)))
     return out
@@ -453,7 +453,7 @@ def conv2d_bwd_weight(x: torch.Tensor, dy: torch.Tensor, dw: torch.Tensor, k: in
     if dw.dtype != torch.float32 or dw.numel() != cout * k * k * Cin or not dw.is_contiguous():
         raise ValueError("dw must be contiguous float32 [Cout,k,k,Cin]")
     d = ConvDesc(B, H, W, Cin, cout, k, k, stride, pad, 0, 0)
-    with torch.cuda.device(x.device):
+    with on_device(x):
         ws = wgrad_workspace(dw.numel(), x.device)
         check(lib().pe_conv2d_bwd_weight_bf16(ctypes.addressof(d), x.data_ptr(), dy.data_ptr(), ldy,
                                               dw.data_ptr(), ws.data_ptr(), ws.numel(),
@@ -467,7 +467,7 @@ def deconv4x4s2_bwd_weight(x: torch.Tensor, dy: torch.Tensor, dw: torch.Tensor) 
     Cout = dy.shape[3]
     if dw.dtype != torch.float32 or dw.numel() != 16 * Cout * Cin:
         raise ValueError("dw must be float32 [4,Cout,4,Cin]")
-    with torch.cuda.device(x.device):
+    with on_device(x):
         ws = wgrad_workspace(dw.numel() // 4, x.device)
         check(lib().pe_deconv4x4s2_bwd_weight_bf16(B, H, W, Cin, Cout, x.data_ptr(), dy.data_ptr(),
                                                    dw.data_ptr(), ws.data_ptr(), ws.numel(),
@@ -479,7 +479,7 @@ def stem7x7s2_bwd_weight(x_s2d: torch.Tensor, dy: torch.Tensor, dw: torch.Tensor
     _check_act(dy, "dy")
     B, H2, W2, _ = x_s2d.shape
     Cout = dy.shape[3]
-    with torch.cuda.device(x_s2d.device):
+    with on_device(x_s2d):
         ws = wgrad_workspace(dw.numel(), x_s2d.device)
         check(lib().pe_stem7x7s2_bwd_weight_bf16(B, H2, W2, Cout, x_s2d.data_ptr(), dy.data_ptr(),
                                                  dw.data_ptr(), ws.data_ptr(), ws.numel(),
@@ -496,7 +496,7 @@ def maxpool3x3s2_bwd(idx: torch.Tensor, dy: torch.Tensor,
     B, Ho, Wo, C = dy.shape
     if out is None:
         out = torch.empty((B, 2 * Ho, 2 * Wo, C), dtype=BF16, device=dy.device)
-    with torch.cuda.device(dy.device):
+    with on_device(dy):
         check(lib().pe_maxpool3x3s2_bwd_bf16(idx.data_ptr(), dy.data_ptr(), B, 2 * Ho, 2 * Wo, C,
                                              out.data_ptr(), _stream(dy)))
     return out
@@ -509,7 +509,7 @@ def final_grad_prepare(g_nchw: torch.Tensor, kpad: int, dbias: Optional[torch.Te
     B, K, H, W = g_nchw.shape
     if out is None:
         out = torch.empty((B, H, W, kpad), dtype=BF16, device=g_nchw.device)
-    with torch.cuda.device(g_nchw.device):
+    with on_device(g_nchw):
         check(lib().pe_final_grad_prepare_bf16(g_nchw.data_ptr(), B, K, H * W, kpad, out.data_ptr(),
                                                _ptr(dbias), _stream(g_nchw)))
     return out
@@ -517,7 +517,7 @@ def final_grad_prepare(g_nchw: torch.Tensor, kpad: int, dbias: Optional[torch.Te
 
 def mul_(a: torch.Tensor, b: torch.Tensor) -> None:
     _need_gpu(a, b)
-    with torch.cuda.device(a.device):
+    with on_device(a):
         check(lib().pe_mul_f32(a.data_ptr(), b.data_ptr(), a.numel(), _stream(a)))
 
 
@@ -534,7 +534,7 @@ def bn_stats(z: torch.Tensor, gamma, beta, eps: float, momentum: float, running_
     M = z.numel() // C
     if out is None:
         out = torch.empty((4, C), dtype=torch.float32, device=z.device)
-    with torch.cuda.device(z.device):
+    with on_device(z):
         check(lib().pe_bn_stats_bf16(z.data_ptr(), M, C, gamma.data_ptr(), beta.data_ptr(), eps,
                                      momentum, _ptr(running_mean), _ptr(running_var),
                                      out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(),
@@ -544,16 +544,18 @@ def bn_stats(z: torch.Tensor, gamma, beta, eps: float, momentum: float, running_
 
 def bn_finalize(ws: torch.Tensor, rows: int, M: int, C: int, gamma, beta, eps: float,
                 momentum: float, running_mean, running_var, out=None):
-    """Second half of bn_stats for partial sums a *_bnstats conv left in `ws`."""
-    _need_gpu(ws, gamma, beta, running_mean, running_var, out)
+    """Second half of bn_stats for partial sums a *_bnstats conv left in `ws`.  `out` may be a
+    float32 [4,C] tensor or a tuple of its four rows (mean, rstd, scale, shift)."""
+    _need_gpu(ws, gamma, beta, running_mean, running_var)
     if out is None:
         out = torch.empty((4, C), dtype=torch.float32, device=ws.device)
-    with torch.cuda.device(ws.device):
+    r = out if isinstance(out, tuple) else out.unbind(0)
+    with on_device(ws):
         check(lib().pe_bn_finalize_bf16(ws.data_ptr(), int(rows), M, C, gamma.data_ptr(),
                                         beta.data_ptr(), eps, momentum, _ptr(running_mean),
-                                        _ptr(running_var), out[0].data_ptr(), out[1].data_ptr(),
-                                        out[2].data_ptr(), out[3].data_ptr(), _stream(ws)))
-    return out[0], out[1], out[2], out[3]
+                                        _ptr(running_var), r[0].data_ptr(), r[1].data_ptr(),
+                                        r[2].data_ptr(), r[3].data_ptr(), _stream(ws)))
+    return r[0], r[1], r[2], r[3]
 
 
 def bn_apply(z: torch.Tensor, scale, shift, residual=None, relu: bool = True,
@@ -563,7 +565,7 @@ def bn_apply(z: torch.Tensor, scale, shift, residual=None, relu: bool = True,
     M = z.numel() // C
     if out is None:
         out = torch.empty_like(z)
-    with torch.cuda.device(z.device):
+    with on_device(z):
         check(lib().pe_bn_apply_bf16(z.data_ptr(), M, C, scale.data_ptr(), shift.data_ptr(),
                                      _ptr(residual), int(relu), out.data_ptr(), _stream(z)))
     return out
@@ -578,7 +580,7 @@ def bn_bwd(da: torch.Tensor, a: Optional[torch.Tensor], z: torch.Tensor, gamma, 
     if dz is None:
         dz = torch.empty_like(z)
     g = torch.empty_like(z) if want_masked else None
-    with torch.cuda.device(z.device):
+    with on_device(z):
         check(lib().pe_bn_bwd_bf16(da.data_ptr(), _ptr(a), z.data_ptr(), M, C, gamma.data_ptr(),
                                    mean.data_ptr(), rstd.data_ptr(), dgamma.data_ptr(),
                                    dbeta.data_ptr(), dz.data_ptr(), _ptr(g), ws.data_ptr(),

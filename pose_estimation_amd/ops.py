@@ -13,8 +13,37 @@ from . import _ffi
 from ._ffi import PE_DTYPE_BF16, PE_DTYPE_F32, check, lib
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_raw_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def _stream(t: torch.Tensor) -> int:
+    """Raw handle of torch's current stream on the tensor's device.  The training loop makes
+    hundreds of launches per step, so this avoids building a torch.cuda.Stream object."""
+    if _raw_stream is not None:
+        idx = t.device.index
+        return _raw_stream(idx if idx is not None else torch.cuda.current_device())
     return torch.cuda.current_stream(t.device).cuda_stream
+
+
+class _NoSwitch:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NO_SWITCH = _NoSwitch()
+
+
+def on_device(t: torch.Tensor):
+    """Context manager that makes the tensor's GPU current for a launch; free when it already
+    is (the usual case: one process per GPU)."""
+    idx = t.device.index
+    if idx is None or (_raw_device is not None and idx == _raw_device()):
+        return _NO_SWITCH
+    return torch.cuda.device(idx)
 
 
 def _need_gpu(*tensors: Optional[torch.Tensor]) -> None:
@@ -158,7 +187,7 @@ def render_vecmaps(joints: torch.Tensor, pairs, H: int, W: int, stride: float, r
         sB, sC, sH, sW = out.stride()
     else:
         sB, sH, sW, sC = out.stride()
-    with torch.cuda.device(joints.device):
+    with on_device(joints):
         check(lib().pe_render_vecmaps_f32(joints.data_ptr(), B, K, pa.ctypes.data, pa.shape[0], H, W,
                                           float(stride), int(radius), out.data_ptr(), sB, sC, sH,
                                           sW, _stream(joints)))
@@ -306,7 +335,7 @@ def adam_step(p: torch.Tensor, m: torch.Tensor, v: torch.Tensor, grad: torch.Ten
                                or not p_bf16.is_contiguous()):
         raise ValueError("p_bf16 must be contiguous bfloat16 of the same length")
     s, a = adam_scalars(lr, beta1, beta2, step, tf1)
-    with torch.cuda.device(p.device):
+    with on_device(p):
         check(lib().pe_adam_step(p.data_ptr(), m.data_ptr(), v.data_ptr(), grad.data_ptr(),
                                  _ptr(p_bf16), p.numel(), beta1, beta2, eps, s, a, grad_scale,
                                  _stream(p)))
@@ -320,6 +349,6 @@ def sgd_step(p: torch.Tensor, mom: torch.Tensor, grad: torch.Tensor, lr: float,
     for t in (p, mom, grad):
         if t.dtype != torch.float32 or not t.is_contiguous() or t.numel() != p.numel():
             raise ValueError("sgd arenas must be contiguous float32 of equal length")
-    with torch.cuda.device(p.device):
+    with on_device(p):
         check(lib().pe_sgd_step(p.data_ptr(), mom.data_ptr(), grad.data_ptr(), _ptr(p_bf16),
                                 p.numel(), lr, momentum, grad_scale, _stream(p)))

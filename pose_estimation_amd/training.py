@@ -47,6 +47,7 @@ class TrainablePoseResNet(PoseResNet):
                 self.wt[c.name] = torch.zeros(c.cin, 1, FINAL_KPAD, dtype=BF16, device=dev)
         self.bn_buf = {c.name: torch.empty(4, c.cout, dtype=torch.float32, device=dev)
                        for c in self.convs if c.bn}
+        self.bn_rows = {k: tuple(v.unbind(0)) for k, v in self.bn_buf.items()}
         self._ws: Optional[torch.Tensor] = None
         self._tplan = None
         stem = self.specs[0]
@@ -122,7 +123,7 @@ class TrainablePoseResNet(PoseResNet):
         _, _, scale, shift = pnn.bn_finalize(self._ws, rows, z.numel() // C, C, self._gamma(c),
                                              self._beta(c), BN_EPS, self.bn_momentum,
                                              self.bn_mean[c.name], self.bn_var[c.name],
-                                             out=self.bn_buf[c.name])
+                                             out=self.bn_rows[c.name])
         return pnn.bn_apply(z, scale, shift, residual, relu)
 
     def _conv_bn(self, c: ConvSpec, x: torch.Tensor, stride=1, pad=0, residual=None, relu=True):
@@ -217,7 +218,7 @@ class TrainablePoseResNet(PoseResNet):
 
     # ------------------------------------------------------------------ backward
     def _bn_bwd(self, c: ConvSpec, da, a, z, want_masked=False):
-        buf = self.bn_buf[c.name]
+        buf = self.bn_rows[c.name]
         return pnn.bn_bwd(da, a, z, self._gamma(c), buf[0], buf[1], self._g(c.name + ".bn.gamma"),
                           self._g(c.name + ".bn.beta"), self._workspace(z), want_masked)
 
