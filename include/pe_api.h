@@ -356,10 +356,11 @@ int32_t pe_mul_f32(float* a, const float* b, int64_t n, pe_stream_t stream);
  *   stats : mean/var (biased) of z per channel -> mean, rstd = 1/sqrt(var+eps),
  *           scale = gamma*rstd, shift = beta - mean*scale; running buffers (may be NULL)
  *           move by `momentum` towards (mean, unbiased var).
- *   apply : y = relu?( z*scale + shift (+ residual) ) in bf16.
- *   bwd   : g = da masked by (a > 0) when a != NULL; dbeta = sum g; dgamma = sum g*xhat;
+ *   apply : y = act( z*scale + shift (+ residual) ) in bf16; relu 0: none, 1: ReLU, 2: ReLU6.
+ *   bwd   : g = da masked by (a > 0) (relu = 1) or (0 < a < 6) (relu = 2) when a != NULL;
+ *           dbeta = sum g; dgamma = sum g*xhat;
  *           dz = gamma*rstd*(g - dbeta/M - xhat*dgamma/M); dmasked (may be NULL) receives g.
- * C must be 8 * a power of two, at most 2048.  workspace: pe_bn_workspace_bytes(M, C).
+ * C must be a multiple of 8, at most 2048.  workspace: pe_bn_workspace_bytes(M, C).
  * Reductions are ordered: results are bit-stable from run to run.
  * ---------------------------------------------------------------------- */
 size_t pe_bn_workspace_bytes(int64_t M, int32_t C);
@@ -370,7 +371,7 @@ int32_t pe_bn_stats_bf16(const void* z, int64_t M, int32_t C, const float* gamma
 int32_t pe_bn_apply_bf16(const void* z, int64_t M, int32_t C, const float* scale,
                          const float* shift, const void* residual, int32_t relu, void* y,
                          pe_stream_t stream);
-int32_t pe_bn_bwd_bf16(const void* da, const void* a, const void* z, int64_t M, int32_t C,
+int32_t pe_bn_bwd_bf16(const void* da, const void* a, int32_t relu, const void* z, int64_t M, int32_t C,
                        const float* gamma, const float* mean, const float* rstd, float* dgamma,
                        float* dbeta, void* dz, void* dmasked, void* workspace,
                        pe_stream_t stream);

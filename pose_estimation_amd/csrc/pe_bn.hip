@@ -16,7 +16,8 @@ constexpr int kBnMaxBlocks = 1024;
 
 struct BnGeom {
     int cg;         // 16-byte channel groups per row (C / 8)
-    int rl;         // rows a workgroup walks in parallel (256 / cg)
+    int rl;         // rows a workgroup walks in parallel (256 / cg, rounded down: threads past
+                    // rl * cg only help with the final fold)
     int rows_blk;   // rows per workgroup
     int nblk;       // workgroups
 };
@@ -52,22 +53,24 @@ __device__ __forceinline__ uint4 pack8(const float* f) {
     return o;
 }
 
-// MODE 0: s1 = sum z, s2 = sum z*z.   MODE 1: g = da * (a > 0 if a given); s1 = sum g, s2 = sum g*z.
-// partial layout: [nblk][2][C].
+// MODE 0: s1 = sum z, s2 = sum z*z.   MODE 1: g = da * (0 < a < act_hi if a given); s1 = sum g,
+// s2 = sum g*z.  act_hi = +inf for ReLU, 6 for ReLU6.  partial layout: [nblk][2][C].
 template <int MODE>
 __global__ __launch_bounds__(256) void bn_reduce_kernel(const uint16_t* __restrict__ z,
                                                         const uint16_t* __restrict__ da,
-                                                        const uint16_t* __restrict__ a, long M,
-                                                        int C, BnGeom g,
+                                                        const uint16_t* __restrict__ a,
+                                                        float act_hi, long M, int C, BnGeom g,
                                                         float* __restrict__ partial) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* red = reinterpret_cast<float*>(smem);  // [rl][2][C]
     const int tid = threadIdx.x;
     const int cgi = tid % g.cg;
     const int rli = tid / g.cg;
+    const bool walker = rli < g.rl;
     const long row0 = (long)blockIdx.x * g.rows_blk;
     long row1 = row0 + g.rows_blk;
     if (row1 > M) row1 = M;
+    if (!walker) row1 = row0;  // no rows for the spare threads
     float s1[8], s2[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) s1[i] = s2[i] = 0.0f;
@@ -107,7 +110,8 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const uint16_t* __restri
                     float af[8];
                     unpack8(av[u], af);
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) gf[i] = af[i] > 0.0f ? gf[i] : 0.0f;
+                    for (int i = 0; i < 8; ++i)
+                        gf[i] = (af[i] > 0.0f && af[i] < act_hi) ? gf[i] : 0.0f;
                 }
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
@@ -117,10 +121,12 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const uint16_t* __restri
             }
         }
     }
+    if (walker) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        red[(rli * 2 + 0) * C + cgi * 8 + i] = s1[i];
-        red[(rli * 2 + 1) * C + cgi * 8 + i] = s2[i];
+        for (int i = 0; i < 8; ++i) {
+            red[(rli * 2 + 0) * C + cgi * 8 + i] = s1[i];
+            red[(rli * 2 + 1) * C + cgi * 8 + i] = s2[i];
+        }
     }
     __syncthreads();
     for (int e = tid; e < 2 * C; e += 256) {
@@ -248,6 +254,10 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const uint16_t* __restric
         if (relu) {
 #pragma unroll
             for (int k = 0; k < 8; ++k) v[k] = fmaxf(v[k], 0.0f);
+            if (relu == 2) {  // ReLU6
+#pragma unroll
+                for (int k = 0; k < 8; ++k) v[k] = fminf(v[k], 6.0f);
+            }
         }
         *reinterpret_cast<uint4*>(y + i * 8) = pack8(v);
     }
@@ -256,8 +266,8 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const uint16_t* __restric
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
     const uint16_t* __restrict__ da, const uint16_t* __restrict__ a, const uint16_t* __restrict__ z,
     long nchunk, int cg, const float* __restrict__ mean, const float* __restrict__ coefA,
-    const float* __restrict__ coefB, const float* __restrict__ coefC, uint16_t* __restrict__ dz,
-    uint16_t* __restrict__ dmasked) {
+    const float* __restrict__ coefB, const float* __restrict__ coefC, float act_hi,
+    uint16_t* __restrict__ dz, uint16_t* __restrict__ dmasked) {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nchunk; i += (long)gridDim.x * 256) {
         const int c0 = (int)(i % cg) * 8;
         float g[8], zf[8];
@@ -267,7 +277,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
             float af[8];
             unpack8(*reinterpret_cast<const uint4*>(a + i * 8), af);
 #pragma unroll
-            for (int k = 0; k < 8; ++k) g[k] = af[k] > 0.0f ? g[k] : 0.0f;
+            for (int k = 0; k < 8; ++k) g[k] = (af[k] > 0.0f && af[k] < act_hi) ? g[k] : 0.0f;
         }
         if (dmasked) *reinterpret_cast<uint4*>(dmasked + i * 8) = pack8(g);
         float o[8];
@@ -289,8 +299,8 @@ static unsigned ew_grid(long nchunk) {
 
 static int32_t bn_check(const char* what, long M, int C) {
     PE_REQUIRE(M > 0 && C > 0, PE_E_INVALID, "%s: M and C must be positive", what);
-    PE_REQUIRE(C % 8 == 0 && C <= 2048 && 256 % (C / 8) == 0, PE_E_UNSUPPORTED,
-               "%s: C must be 8 * a power of two, at most 2048 (C = %d)", what, C);
+    PE_REQUIRE(C % 8 == 0 && C <= 2048, PE_E_UNSUPPORTED,
+               "%s: C must be a multiple of 8, at most 2048 (C = %d)", what, C);
     return PE_OK;
 }
 
@@ -299,7 +309,7 @@ static int32_t bn_check(const char* what, long M, int C) {
 using namespace pe;
 
 extern "C" size_t pe_bn_workspace_bytes(int64_t M, int32_t C) {
-    if (M <= 0 || C <= 0 || C % 8 != 0 || C > 2048 || 256 % (C / 8) != 0) return 16;
+    if (M <= 0 || C <= 0 || C % 8 != 0 || C > 2048) return 16;
     // per-block partials (or one row per 64-pixel conv tile when the statistics come from the
     // conv epilogue) + three per-channel coefficient rows for the backward pass
     size_t rows = (size_t)(M / 64) + 8;
@@ -342,7 +352,7 @@ extern "C" int32_t pe_bn_stats_bf16(const void* z, int64_t M, int32_t C, const f
     float* partial = static_cast<float*>(workspace);
     hipStream_t st = as_stream(stream);
     bn_reduce_kernel<0><<<g.nblk, 256, (size_t)g.rl * 2 * C * sizeof(float), st>>>(
-        static_cast<const uint16_t*>(z), nullptr, nullptr, M, C, g, partial);
+        static_cast<const uint16_t*>(z), nullptr, nullptr, 0.0f, M, C, g, partial);
     rc = check_launch("pe_bn_stats_bf16(reduce)");
     if (rc != PE_OK) return rc;
     const BnFwdOut o{mean, rstd, scale, shift, running_mean, running_var};
@@ -369,8 +379,8 @@ extern "C" int32_t pe_bn_apply_bf16(const void* z, int64_t M, int32_t C, const f
     return check_launch("pe_bn_apply_bf16");
 }
 
-extern "C" int32_t pe_bn_bwd_bf16(const void* da, const void* a, const void* z, int64_t M,
-                                  int32_t C, const float* gamma, const float* mean,
+extern "C" int32_t pe_bn_bwd_bf16(const void* da, const void* a, int32_t relu, const void* z,
+                                  int64_t M, int32_t C, const float* gamma, const float* mean,
                                   const float* rstd, float* dgamma, float* dbeta, void* dz,
                                   void* dmasked, void* workspace, pe_stream_t stream) {
     int32_t rc = bn_check("pe_bn_bwd_bf16", M, C);
@@ -380,6 +390,9 @@ extern "C" int32_t pe_bn_bwd_bf16(const void* da, const void* a, const void* z, 
     PE_REQUIRE(aligned(da, 16) && aligned(a, 16) && aligned(z, 16) && aligned(dz, 16) &&
                    aligned(dmasked, 16),
                PE_E_INVALID, "pe_bn_bwd_bf16: tensors must be 16-byte aligned");
+    PE_REQUIRE(relu == 1 || relu == 2, PE_E_INVALID,
+               "pe_bn_bwd_bf16: relu must be 1 (ReLU) or 2 (ReLU6); it only matters when a is given");
+    const float act_hi = relu == 2 ? 6.0f : INFINITY;
     const BnGeom g = bn_geom(M, C);
     float* partial = static_cast<float*>(workspace);
     float* coefA = partial + (size_t)kBnMaxBlocks * 2 * C;
@@ -388,7 +401,7 @@ extern "C" int32_t pe_bn_bwd_bf16(const void* da, const void* a, const void* z, 
     hipStream_t st = as_stream(stream);
     bn_reduce_kernel<1><<<g.nblk, 256, (size_t)g.rl * 2 * C * sizeof(float), st>>>(
         static_cast<const uint16_t*>(z), static_cast<const uint16_t*>(da),
-        static_cast<const uint16_t*>(a), M, C, g, partial);
+        static_cast<const uint16_t*>(a), act_hi, M, C, g, partial);
     rc = check_launch("pe_bn_bwd_bf16(reduce)");
     if (rc != PE_OK) return rc;
     bn_bwd_finalize_kernel<<<(C + kFoldCh - 1) / kFoldCh, 256, 0, st>>>(partial, g.nblk, C,
@@ -399,7 +412,7 @@ extern "C" int32_t pe_bn_bwd_bf16(const void* da, const void* a, const void* z, 
     const long nchunk = M * (C / 8);
     bn_bwd_apply_kernel<<<ew_grid(nchunk), 256, 0, st>>>(
         static_cast<const uint16_t*>(da), static_cast<const uint16_t*>(a),
-        static_cast<const uint16_t*>(z), nchunk, C / 8, mean, coefA, coefB, coefC,
+        static_cast<const uint16_t*>(z), nchunk, C / 8, mean, coefA, coefB, coefC, act_hi,
         static_cast<uint16_t*>(dz), static_cast<uint16_t*>(dmasked));
     return check_launch("pe_bn_bwd_bf16(apply)");
 }

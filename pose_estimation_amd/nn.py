@@ -558,7 +558,7 @@ def bn_finalize(ws: torch.Tensor, rows: int, M: int, C: int, gamma, beta, eps: f
     return r[0], r[1], r[2], r[3]
 
 
-def bn_apply(z: torch.Tensor, scale, shift, residual=None, relu: bool = True,
+def bn_apply(z: torch.Tensor, scale, shift, residual=None, relu: int = 1,
              out: Optional[torch.Tensor] = None) -> torch.Tensor:
     _check_act(z, "z")
     C = z.shape[3]
@@ -572,8 +572,9 @@ def bn_apply(z: torch.Tensor, scale, shift, residual=None, relu: bool = True,
 
 
 def bn_bwd(da: torch.Tensor, a: Optional[torch.Tensor], z: torch.Tensor, gamma, mean, rstd,
-           dgamma, dbeta, ws: torch.Tensor, want_masked: bool = False, dz=None):
-    """Returns (dz, g) where g = da masked by the ReLU (None unless want_masked)."""
+           dgamma, dbeta, ws: torch.Tensor, want_masked: bool = False, dz=None, relu: int = 1):
+    """Returns (dz, g) where g = da masked by the activation that produced `a` (relu 1: ReLU,
+    2: ReLU6; no mask when a is None); g is None unless want_masked."""
     _check_act(da, "da")
     C = z.shape[3]
     M = z.numel() // C
@@ -581,7 +582,8 @@ def bn_bwd(da: torch.Tensor, a: Optional[torch.Tensor], z: torch.Tensor, gamma, 
         dz = torch.empty_like(z)
     g = torch.empty_like(z) if want_masked else None
     with on_device(z):
-        check(lib().pe_bn_bwd_bf16(da.data_ptr(), _ptr(a), z.data_ptr(), M, C, gamma.data_ptr(),
+        check(lib().pe_bn_bwd_bf16(da.data_ptr(), _ptr(a), int(relu), z.data_ptr(), M, C,
+                                   gamma.data_ptr(),
                                    mean.data_ptr(), rstd.data_ptr(), dgamma.data_ptr(),
                                    dbeta.data_ptr(), dz.data_ptr(), _ptr(g), ws.data_ptr(),
                                    _stream(z)))

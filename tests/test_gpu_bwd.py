@@ -226,6 +226,40 @@ def test_batch_norm_forward_backward(shape):
     assert torch.equal(dz, dz2)
 
 
+@pytest.mark.parametrize("shape", [(3, 10, 10, 96), (2, 12, 8, 24), (2, 6, 5, 1000)])
+def test_batch_norm_relu6_any_channel_count(shape):
+    """ReLU6 masks (0 < a < 6) and channel counts that are multiples of 8 but not 8 * 2^n."""
+    B, H, W, C = shape
+    g = torch.Generator().manual_seed(53 + C)
+    z = to.bf16r(rnd(shape, g) * 3 + 2.0)
+    gamma = torch.rand(C, generator=g) * 2 + 1.0
+    beta = torch.randn(C, generator=g) + 2.0
+    da = rnd(shape, g)
+    M = B * H * W
+    zd = nchw(z).double().requires_grad_(True)
+    gd = gamma.double().requires_grad_(True)
+    bd = beta.double().requires_grad_(True)
+    y = F.batch_norm(zd, None, None, gd, bd, training=True, eps=1e-5)
+    a_ref = torch.clamp(y, 0.0, 6.0)
+    ws = pnn.bn_workspace(M, C, "cuda")
+    zg = z.to(BF16).cuda()
+    mean, rstd, scale, shift = pnn.bn_stats(zg, gamma.cuda(), beta.cuda(), 1e-5, 0.1, None, None, ws)
+    a = pnn.bn_apply(zg, scale, shift, None, relu=2)
+    close(a.float().cpu(), nhwc(a_ref).float(), 4e-3)
+    af = a.float().cpu()
+    assert af.max().item() == 6.0 and af.min().item() == 0.0   # both clamps are exercised
+    mask = ((af > 0) & (af < 6)).double()
+    (y * nchw(mask) * nchw(da).double()).sum().backward()
+    dgamma = torch.empty(C, device="cuda")
+    dbeta = torch.empty(C, device="cuda")
+    dz, gm = pnn.bn_bwd(da.to(BF16).cuda(), a, zg, gamma.cuda(), mean, rstd, dgamma, dbeta, ws,
+                        want_masked=True, relu=2)
+    close(dz.float().cpu(), nhwc(zd.grad).float(), 6e-3)
+    assert torch.allclose(dgamma.cpu(), gd.grad.float(), rtol=2e-3, atol=2e-3 * gd.grad.abs().max().item())
+    assert torch.allclose(dbeta.cpu(), bd.grad.float(), rtol=2e-3, atol=2e-3 * bd.grad.abs().max().item())
+    assert torch.equal(gm.float().cpu(), (da * mask.float()))
+
+
 @pytest.mark.parametrize("cfg", [
     # kind, B, H, W, Cin, Cout, k, stride, pad
     ("conv", 4, 16, 12, 64, 64, 1, 1, 0),
