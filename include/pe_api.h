@@ -297,6 +297,15 @@ int32_t pe_maxpool3x3s2_bwd_bf16(const uint8_t* idx, const void* dy, int32_t B, 
 int32_t pe_conv2d_bwd_data_bf16(const pe_conv_desc* d, const void* dy, const void* w_t,
                                 const void* residual, void* dx, pe_stream_t stream);
 
+/* When the forward conv has 8, 16 or 32 OUTPUT channels, one 64-element K run of the
+ * backward-data GEMM spans P = 64/Cout adjacent dy pixels and w_t is [Cin][nslots][P*Cout]:
+ * filter tap (kh, kw) lives in sub-block sub_of_tap[kh*KW+kw] (Cout elements) of slot
+ * slot_of_tap[kh*KW+kw]; sub-blocks no tap maps to must hold zeros.  This call returns that
+ * mapping (host arrays of KH*KW entries) and the slot count for a filter geometry. */
+int32_t pe_conv2d_bwd_data_narrow_layout(int32_t KH, int32_t KW, int32_t stride, int32_t pad,
+                                         int32_t Cout, int32_t* slot_of_tap, int32_t* sub_of_tap,
+                                         int32_t* nslots);
+
 /* Backward-data of the 4x4/2 transposed conv: dy [B,2H,2W,Cout], w_t [Cin][16][Cout] where
  * slot = phase*4 + tap of the forward packing; dx [B,H,W,Cin]. */
 int32_t pe_deconv4x4s2_bwd_data_bf16(int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout,
@@ -308,7 +317,10 @@ int32_t pe_deconv4x4s2_bwd_data_bf16(int32_t B, int32_t H, int32_t W, int32_t Ci
  * dw into `workspace` (device memory, at least pe_wgrad_workspace_bytes(elements of the
  * largest dw passed)) and an ordered reduction folds them, so results are bit-stable from run
  * to run.  ldy = channels per pixel of dy (>= Cout rounded up to 8; lets a zero-padded
- * gradient of a narrow layer be used). */
+ * gradient of a narrow layer be used).  With 8, 16 or 32 input channels dw has the forward
+ * conv's narrow packing [Cout][KH][ceil(KW/P)][P*Cin]; elements of a run that lie past the filter
+ * width receive values that carry no parameter and the caller masks them off (the stems'
+ * structural zeros behave the same way). */
 size_t pe_wgrad_workspace_bytes(int64_t weight_elems);
 int32_t pe_conv2d_bwd_weight_bf16(const pe_conv_desc* d, const void* x, const void* dy,
                                   int32_t ldy, float* dw, void* workspace,
@@ -321,6 +333,11 @@ int32_t pe_stem7x7s2_bwd_weight_bf16(int32_t B, int32_t H2, int32_t W2, int32_t 
                                      const void* x_s2d, const void* dy, float* dw,
                                      void* workspace, size_t workspace_bytes,
                                      pe_stream_t stream);
+/* Same for the 3x3/2 stem of pe_stem3x3s2_fwd_bf16 (dw [Cout][2][64]). */
+int32_t pe_stem3x3s2_bwd_weight_bf16(int32_t B, int32_t H2, int32_t W2, int32_t Cout,
+                                     const void* x_s2d, const void* dy, float* dw,
+                                     void* workspace, size_t workspace_bytes,
+                                     pe_stream_t stream);
 
 /* out[c][t0 + t][a] = in[a][t][c] (bf16), out rows are slots*apitch elements long.  Builds the
  * backward-data weight layouts from the forward packings. */
@@ -329,13 +346,16 @@ int32_t pe_transpose_weights_bf16(const void* in, int32_t A, int32_t T, int32_t 
 
 /* The same transpose for many weights in one launch.  jobs_device: DEVICE array of njobs
  * records; tile_begin is the running sum of T * ceil(A/64) * ceil(C/64) over the jobs before
- * it (ascending), total_tiles the sum over all jobs. */
+ * it (ascending), total_tiles the sum over all jobs.  A job may move a window of the source's
+ * taps (src_T, src_t0): out[c][t0 + t][a] = in[a][src_t0 + t][c], t < T. */
 typedef struct pe_transpose_job {
     const void* in;   /* [A][T][C] bf16 */
     void* out;        /* [C][slots][apitch] bf16 */
     int32_t A, T, C, slots, apitch, t0;
     int32_t tile_begin;
-    int32_t reserved;
+    int16_t src_T;    /* taps per row of the source when the job moves only a window of them
+                         (source is [A][src_T][C]); 0 = T */
+    int16_t src_t0;   /* first source tap of the window */
 } pe_transpose_job;
 
 int32_t pe_transpose_weights_batched_bf16(const pe_transpose_job* jobs_device, int32_t njobs,
@@ -395,6 +415,10 @@ int32_t pe_stem7x7s2_fwd_bnstats_bf16(int32_t B, int32_t H2, int32_t W2, int32_t
                                       const void* x_s2d, const void* w, void* y,
                                       void* bn_workspace, size_t workspace_bytes,
                                       int32_t* rows_out, pe_stream_t stream);
+int32_t pe_stem3x3s2_fwd_bnstats_bf16(int32_t B, int32_t H2, int32_t W2, int32_t Cout,
+                                      const void* x_s2d, const void* w, void* y,
+                                      void* bn_workspace, size_t workspace_bytes,
+                                      int32_t* rows_out, pe_stream_t stream);
 int32_t pe_bn_finalize_bf16(const void* workspace, int32_t rows, int64_t M, int32_t C,
                             const float* gamma, const float* beta, float eps, float momentum,
                             float* running_mean, float* running_var, float* mean, float* rstd,
@@ -411,6 +435,20 @@ int32_t pe_bn_finalize_bf16(const void* workspace, int32_t rows, int64_t M, int3
 int32_t pe_fuse_upsample_add_bf16(const void* base, int32_t n_low, const void* const* low_host,
                                   const int32_t* log2_factor_host, int32_t B, int32_t H,
                                   int32_t W, int32_t C, int32_t relu, void* y, pe_stream_t stream);
+
+/* Backward of the fusion.  dy, y (the forward output; NULL when the forward had no ReLU) and
+ * dbase are bf16 NHWC [B,H,W,C]; g = dy where y > 0, else 0 (g = dy without a ReLU).
+ * dbase (may be NULL; must be NULL when y is NULL, since then the gradient of base is dy
+ * itself) receives g; dlow_host[i] receives the sum of g over each 2^f_i x 2^f_i block,
+ * [B, H >> f_i, W >> f_i, C], added in float32 in row-major order and rounded once. */
+int32_t pe_fuse_upsample_add_bwd_bf16(const void* dy, const void* y, int32_t n_low,
+                                      void* const* dlow_host, const int32_t* log2_factor_host,
+                                      int32_t B, int32_t H, int32_t W, int32_t C, void* dbase,
+                                      pe_stream_t stream);
+
+/* out = a + b over n bf16 elements (n a multiple of 8), summed in float32, rounded once: the
+ * accumulation of gradients that reach one activation from two consumers. */
+int32_t pe_add_bf16(const void* a, const void* b, int64_t n, void* out, pe_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * Detection branch: per-anchor targets from ground-truth boxes, and the loss on them.

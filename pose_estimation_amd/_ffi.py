@@ -144,6 +144,20 @@ SIGNATURES = {
         c_int32, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p],
     ),
     "pe_mul_f32": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p]),
+    "pe_stem3x3s2_bwd_weight_bf16": (
+        c_int32,
+        [c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
+         c_void_p],
+    ),
+    "pe_stem3x3s2_fwd_bnstats_bf16": (
+        c_int32, [c_int32] * 4 + [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p,
+                                  c_void_p]),
+    "pe_conv2d_bwd_data_narrow_layout": (
+        c_int32, [c_int32] * 5 + [c_void_p, c_void_p, c_void_p]),
+    "pe_fuse_upsample_add_bwd_bf16": (
+        c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_int32, c_int32,
+                  c_int32, c_void_p, c_void_p]),
+    "pe_add_bf16": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
     "pe_fuse_upsample_add_bf16": (
         c_int32, [c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32,
                   c_int32, c_void_p, c_void_p]),

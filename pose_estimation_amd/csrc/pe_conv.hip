@@ -331,10 +331,10 @@ extern "C" int32_t pe_stem7x7s2_fwd_bnstats_bf16(int32_t B, int32_t H2, int32_t 
     return stem7_fwd_impl(B, H2, W2, Cout, 0, x_s2d, w, nullptr, nullptr, y, &sr, stream);
 }
 
-extern "C" int32_t pe_stem3x3s2_fwd_bf16(int32_t B, int32_t H2, int32_t W2, int32_t Cout,
-                                         int32_t relu, const void* x_s2d, const void* w,
-                                         const float* scale, const float* shift, void* y,
-                                         pe_stream_t stream) {
+static int32_t stem3_fwd_impl(int32_t B, int32_t H2, int32_t W2, int32_t Cout, int32_t relu,
+                              const void* x_s2d, const void* w, const float* scale,
+                              const float* shift, void* y, const StatReq* sr,
+                              pe_stream_t stream) {
     PE_REQUIRE(B > 0 && H2 > 0 && W2 > 0 && Cout > 0, PE_E_INVALID,
                "pe_stem3x3s2_fwd_bf16: sizes must be positive");
     IgemmParams p;
@@ -363,7 +363,24 @@ extern "C" int32_t pe_stem3x3s2_fwd_bf16(int32_t B, int32_t H2, int32_t W2, int3
     p.OW = W2;
     p.ldc = Cout;
     p.relu = relu;
+    const int32_t rc = attach_stats(p, sr, "pe_stem3x3s2_fwd_bf16");
+    if (rc != PE_OK) return rc;
     return igemm_launch(p, as_stream(stream), "pe_stem3x3s2_fwd_bf16");
+}
+
+extern "C" int32_t pe_stem3x3s2_fwd_bf16(int32_t B, int32_t H2, int32_t W2, int32_t Cout,
+                                         int32_t relu, const void* x_s2d, const void* w,
+                                         const float* scale, const float* shift, void* y,
+                                         pe_stream_t stream) {
+    return stem3_fwd_impl(B, H2, W2, Cout, relu, x_s2d, w, scale, shift, y, nullptr, stream);
+}
+
+extern "C" int32_t pe_stem3x3s2_fwd_bnstats_bf16(int32_t B, int32_t H2, int32_t W2, int32_t Cout,
+                                                 const void* x_s2d, const void* w, void* y,
+                                                 void* bn_workspace, size_t workspace_bytes,
+                                                 int32_t* rows_out, pe_stream_t stream) {
+    const StatReq sr{bn_workspace, workspace_bytes, rows_out};
+    return stem3_fwd_impl(B, H2, W2, Cout, 0, x_s2d, w, nullptr, nullptr, y, &sr, stream);
 }
 
 extern "C" int32_t pe_preprocess_u8_s2d_bf16(const uint8_t* img, int32_t B, int32_t H, int32_t W,

@@ -54,6 +54,8 @@ __global__ __launch_bounds__(256) void transpose_w_batched_kernel(const pe_trans
     __syncthreads();
     const pe_transpose_job jb = jobs[job_s];
     const int A = jb.A, T = jb.T, C = jb.C;
+    // the job's taps may be a window [src_t0, src_t0 + T) of a wider source [A][src_T][C]
+    const int srcT = jb.src_T > 0 ? jb.src_T : T;
     const int ntc = (C + 63) / 64, nta = (A + 63) / 64;
     int local = blockIdx.x - jb.tile_begin;
     const int t = local / (ntc * nta);
@@ -67,7 +69,8 @@ __global__ __launch_bounds__(256) void transpose_w_batched_kernel(const pe_trans
     const int ty = threadIdx.x >> 6;
     for (int r = ty; r < 64; r += 4) {
         const int a = a0 + r, c = c0 + tx;
-        tile[r][tx] = (a < A && c < C) ? in[((long)a * T + t) * C + c] : (uint16_t)0;
+        tile[r][tx] =
+            (a < A && c < C) ? in[((long)a * srcT + jb.src_t0 + t) * C + c] : (uint16_t)0;
     }
     __syncthreads();
     for (int r = ty; r < 64; r += 4) {
@@ -202,6 +205,54 @@ __global__ __launch_bounds__(256) void mul_f32_kernel(float* __restrict__ a,
 
 using namespace pe;
 
+// Backward-data of a conv whose OUTPUT has 8, 16 or 32 channels: the gradient dy is the GEMM's
+// "activation" operand and one 64-element K run then spans P = 64/Cout horizontally adjacent dy
+// pixels.  Inside one input-parity class (py, px) and one filter row kh, the taps kw that reach
+// that class read dy columns (px + pad - kw) / s; sorted by that offset they are grouped into
+// runs of P adjacent columns.  A run is one engine tap and owns one slot of the re-packed
+// weights w_t [Cin][slots][P * Cout]; (kh, kw) sits in sub-block `sub` of its run's slot, and
+// sub-blocks no tap reaches hold zeros.  Slots are numbered py, px, kh, run, in that order.
+// Returns the slot count (0 when it does not fit the tap table).
+static int narrow_bwd_layout(int KH, int KW, int s, int pad, int P, int32_t* slot_of_tap,
+                             int32_t* sub_of_tap) {
+    int nslot = 0;
+    for (int py = 0; py < s; ++py)
+        for (int px = 0; px < s; ++px)
+            for (int kh = 0; kh < KH; ++kh) {
+                if ((py + pad - kh) % s != 0) continue;
+                // kw descending = dy column offset ascending
+                int run_start = 0;
+                bool open = false;
+                for (int kw = KW - 1; kw >= 0; --kw) {
+                    if ((px + pad - kw) % s != 0) continue;
+                    const int off = (px + pad - kw) / s;
+                    if (!open || off >= run_start + P) {
+                        run_start = off;
+                        open = true;
+                        ++nslot;
+                    }
+                    if (slot_of_tap) {
+                        slot_of_tap[kh * KW + kw] = nslot - 1;
+                        sub_of_tap[kh * KW + kw] = off - run_start;
+                    }
+                }
+            }
+    return nslot;
+}
+
+extern "C" int32_t pe_conv2d_bwd_data_narrow_layout(int32_t KH, int32_t KW, int32_t stride,
+                                                    int32_t pad, int32_t Cout,
+                                                    int32_t* slot_of_tap, int32_t* sub_of_tap,
+                                                    int32_t* nslots) {
+    PE_REQUIRE(Cout == 8 || Cout == 16 || Cout == 32, PE_E_INVALID,
+               "pe_conv2d_bwd_data_narrow_layout: Cout must be 8, 16 or 32");
+    PE_REQUIRE(KH > 0 && KW > 0 && KH * KW <= kMaxTaps && (stride == 1 || stride == 2) && pad >= 0 &&
+                   slot_of_tap && sub_of_tap && nslots,
+               PE_E_INVALID, "pe_conv2d_bwd_data_narrow_layout: bad arguments");
+    *nslots = narrow_bwd_layout(KH, KW, stride, pad, 64 / Cout, slot_of_tap, sub_of_tap);
+    return PE_OK;
+}
+
 extern "C" int32_t pe_conv2d_bwd_data_bf16(const pe_conv_desc* d, const void* dy, const void* w_t,
                                            const void* residual, void* dx, pe_stream_t stream) {
     PE_REQUIRE(d != nullptr, PE_E_INVALID, "pe_conv2d_bwd_data_bf16: NULL descriptor");
@@ -217,6 +268,15 @@ extern "C" int32_t pe_conv2d_bwd_data_bf16(const pe_conv_desc* d, const void* dy
     PE_REQUIRE(Ho > 0 && Wo > 0, PE_E_INVALID, "pe_conv2d_bwd_data_bf16: empty output");
     hipStream_t st = as_stream(stream);
     const int T = d->KH * d->KW;
+    const bool narrow = d->Cout == 8 || d->Cout == 16 || d->Cout == 32;
+    const int P = narrow ? 64 / d->Cout : 1;
+    int32_t slot_of[kMaxTaps], sub_of[kMaxTaps];
+    int nslots = T;
+    if (narrow) {
+        nslots = narrow_bwd_layout(d->KH, d->KW, s, d->pad, P, slot_of, sub_of);
+        PE_REQUIRE(nslots <= kMaxTaps, PE_E_UNSUPPORTED,
+                   "pe_conv2d_bwd_data_bf16: filter %dx%d not supported", d->KH, d->KW);
+    }
 
     // which phases have taps?
     bool need_zero = false;
@@ -245,15 +305,25 @@ extern "C" int32_t pe_conv2d_bwd_data_bf16(const pe_conv_desc* d, const void* dy
             const int Hp = (d->H - py + s - 1) / s, Wp = (d->W - px + s - 1) / s;
             if (Hp <= 0 || Wp <= 0) continue;
             const int tstart = t;
-            for (int kh = 0; kh < d->KH; ++kh)
-                for (int kw = 0; kw < d->KW; ++kw) {
+            for (int kh = 0; kh < d->KH; ++kh) {
+                int last_slot = -1;
+                for (int i = 0; i < d->KW; ++i) {
+                    const int kw = narrow ? d->KW - 1 - i : i;  // narrow: dy column ascending
                     const int ny = py + d->pad - kh, nx = px + d->pad - kw;
                     if ((ny % s) != 0 || (nx % s) != 0) continue;
+                    if (narrow) {
+                        // one engine tap per run: the tap that opens the run (sub-block 0)
+                        if (slot_of[kh * d->KW + kw] == last_slot) continue;
+                        last_slot = slot_of[kh * d->KW + kw];
+                        p.tap_slot[t] = (uint8_t)last_slot;
+                    } else {
+                        p.tap_slot[t] = (uint8_t)(kh * d->KW + kw);
+                    }
                     p.tap_dy[t] = (int16_t)(ny / s);
                     p.tap_dx[t] = (int16_t)(nx / s);
-                    p.tap_slot[t] = (uint8_t)(kh * d->KW + kw);
                     ++t;
                 }
+            }
             if (t == tstart) continue;
             p.ph_t0[nph] = (int16_t)tstart;
             p.ph_T[nph] = (int16_t)(t - tstart);
@@ -274,9 +344,13 @@ extern "C" int32_t pe_conv2d_bwd_data_bf16(const pe_conv_desc* d, const void* dy
     p.Hi = Ho;
     p.Wi = Wo;
     p.Cx = d->Cout;
-    p.Cin = d->Cout;
+    p.Cin = narrow ? 64 : d->Cout;
+    if (narrow) {
+        p.cshift = d->Cout == 8 ? 3 : (d->Cout == 16 ? 4 : 5);
+        p.cmask = d->Cout - 1;
+    }
     p.N = d->Cin;
-    p.wk_row = T * d->Cout;
+    p.wk_row = nslots * p.Cin;
     p.OH = d->H;
     p.OW = d->W;
     p.osy = p.osx = s;
@@ -345,18 +419,37 @@ extern "C" int32_t pe_conv2d_bwd_weight_bf16(const pe_conv_desc* d, const void* 
     p.Hi = d->H;
     p.Wi = d->W;
     p.Cx = d->Cin;
-    p.Cin = d->Cin;
     p.Ho = Ho;
     p.Wo = Wo;
     p.sy = p.sx = d->stride;
     p.N = Npad;
     p.Nw = d->Cout;
-    p.T = d->KH * d->KW;
-    for (int kh = 0; kh < d->KH; ++kh)
-        for (int kw = 0; kw < d->KW; ++kw) {
-            p.tap_dy[kh * d->KW + kw] = (int16_t)(kh - d->pad);
-            p.tap_dx[kh * d->KW + kw] = (int16_t)(kw - d->pad);
-        }
+    if (d->Cin == 8 || d->Cin == 16 || d->Cin == 32) {
+        // narrow inputs: dw comes out in the forward conv's narrow packing
+        // [Cout][KH][ceil(KW/P)][P*Cin]; elements of runs that reach past the filter receive the
+        // correlation with the pixel beyond it and must be masked off by the caller
+        const int P = 64 / d->Cin;
+        const int KWc = (d->KW + P - 1) / P;
+        PE_REQUIRE(d->KH * KWc <= kMaxTaps, PE_E_UNSUPPORTED,
+                   "pe_conv2d_bwd_weight_bf16: filter %dx%d not supported", d->KH, d->KW);
+        p.Cin = 64;
+        p.cshift = d->Cin == 8 ? 3 : (d->Cin == 16 ? 4 : 5);
+        p.cmask = d->Cin - 1;
+        p.T = d->KH * KWc;
+        for (int kh = 0; kh < d->KH; ++kh)
+            for (int c = 0; c < KWc; ++c) {
+                p.tap_dy[kh * KWc + c] = (int16_t)(kh - d->pad);
+                p.tap_dx[kh * KWc + c] = (int16_t)(c * P - d->pad);
+            }
+    } else {
+        p.Cin = d->Cin;
+        p.T = d->KH * d->KW;
+        for (int kh = 0; kh < d->KH; ++kh)
+            for (int kw = 0; kw < d->KW; ++kw) {
+                p.tap_dy[kh * d->KW + kw] = (int16_t)(kh - d->pad);
+                p.tap_dx[kh * d->KW + kw] = (int16_t)(kw - d->pad);
+            }
+    }
     p.OH = Ho;
     p.OW = Wo;
     p.ldy = ldy;
@@ -438,6 +531,40 @@ extern "C" int32_t pe_stem7x7s2_bwd_weight_bf16(int32_t B, int32_t H2, int32_t W
     p.ldy = Cout;
     return wgrad_launch(p, workspace, workspace_bytes, as_stream(stream),
                         "pe_stem7x7s2_bwd_weight_bf16");
+}
+
+extern "C" int32_t pe_stem3x3s2_bwd_weight_bf16(int32_t B, int32_t H2, int32_t W2, int32_t Cout,
+                                                const void* x_s2d, const void* dy, float* dw,
+                                                void* workspace, size_t workspace_bytes,
+                                                pe_stream_t stream) {
+    PE_REQUIRE(B > 0 && H2 > 0 && W2 > 0 && Cout > 0, PE_E_INVALID,
+               "pe_stem3x3s2_bwd_weight_bf16: sizes must be positive");
+    WgradParams p;
+    wgrad_defaults(p);
+    p.x = static_cast<const uint16_t*>(x_s2d);
+    p.dy = static_cast<const uint16_t*>(dy);
+    p.dw = dw;
+    p.B = B;
+    p.Hi = H2;
+    p.Wi = W2;
+    p.Cx = 16;
+    p.Cin = 64;
+    p.cshift = 4;
+    p.cmask = 15;
+    p.Ho = H2;
+    p.Wo = W2;
+    p.N = (Cout + 7) / 8 * 8;
+    p.Nw = Cout;
+    p.T = 2;
+    for (int r = 0; r < 2; ++r) {
+        p.tap_dy[r] = (int16_t)(r - 1);
+        p.tap_dx[r] = -1;
+    }
+    p.OH = H2;
+    p.OW = W2;
+    p.ldy = Cout;
+    return wgrad_launch(p, workspace, workspace_bytes, as_stream(stream),
+                        "pe_stem3x3s2_bwd_weight_bf16");
 }
 
 extern "C" int32_t pe_transpose_weights_bf16(const void* in, int32_t A, int32_t T, int32_t C,

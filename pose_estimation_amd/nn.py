@@ -191,14 +191,21 @@ def stem7x7s2(x_s2d: torch.Tensor, w: torch.Tensor, scale=None, shift=None, relu
 
 
 def conv2d_bnstats(x: torch.Tensor, w: torch.Tensor, ws: torch.Tensor, stride: int = 1,
-                   pad: int = 0, out: Optional[torch.Tensor] = None):
+                   pad: int = 0, out: Optional[torch.Tensor] = None, kw: Optional[int] = None):
     """z = conv(x, w) with the per-channel sums of z and z*z left in `ws` as one partial row per
-    GEMM tile; returns (z, rows) for bn_finalize."""
+    GEMM tile; returns (z, rows) for bn_finalize.  Narrow inputs (8, 16, 32 channels): as conv2d."""
     _check_act(x)
     _need_gpu(w, ws, out)
     B, H, W, Cin = x.shape
     Cout, KH, KW, Cin2 = w.shape
-    if Cin2 != Cin or w.dtype != BF16 or not w.is_contiguous():
+    if Cin in (8, 16, 32):
+        P = 64 // Cin
+        if kw is None or Cin2 != 64 or KW != (kw + P - 1) // P:
+            raise ValueError("narrow conv: w must be [Cout,KH,ceil(kw/P),64] and kw given")
+        KW = kw
+    elif Cin2 != Cin:
+        raise ValueError("w must be contiguous bfloat16 [Cout,KH,KW,Cin]")
+    if w.dtype != BF16 or not w.is_contiguous():
         raise ValueError("w must be contiguous bfloat16 [Cout,KH,KW,Cin]")
     Ho = (H + 2 * pad - KH) // stride + 1
     Wo = (W + 2 * pad - KW) // stride + 1
@@ -288,6 +295,25 @@ def stem3x3s2(x_s2d: torch.Tensor, w: torch.Tensor, scale=None, shift=None, relu
     return out
 
 
+def stem3x3s2_bnstats(x_s2d: torch.Tensor, w: torch.Tensor, ws: torch.Tensor,
+                      out: Optional[torch.Tensor] = None):
+    """stem3x3s2 without an epilogue, plus the statistics partials (see conv2d_bnstats)."""
+    _check_act(x_s2d, "x_s2d")
+    _need_gpu(w, ws, out)
+    B, H2, W2, c16 = x_s2d.shape
+    if c16 != 16 or tuple(w.shape[1:]) != (2, 64) or w.dtype != BF16:
+        raise ValueError("stem3x3s2 expects x_s2d [B,H/2,W/2,16] and w bf16 [Cout,2,64]")
+    Cout = w.shape[0]
+    if out is None:
+        out = torch.empty((B, H2, W2, Cout), dtype=BF16, device=x_s2d.device)
+    rows = ctypes.c_int32(0)
+    with on_device(x_s2d):
+        check(lib().pe_stem3x3s2_fwd_bnstats_bf16(B, H2, W2, Cout, x_s2d.data_ptr(), w.data_ptr(),
+                                                  out.data_ptr(), ws.data_ptr(), ws.numel(),
+                                                  ctypes.byref(rows), _stream(x_s2d)))
+    return out, rows.value
+
+
 def depthwise3x3(x: torch.Tensor, w9c: torch.Tensor, scale=None, shift=None, stride: int = 1,
                  dilation: int = 1, relu: int = 2, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Depthwise 3x3 conv with pad = dilation.  x [B,H,W,C] bf16, w9c [9,C] bf16."""
@@ -358,7 +384,8 @@ class TransposePlan:
 
     _DTYPE = np.dtype([("in", np.uint64), ("out", np.uint64), ("A", np.int32), ("T", np.int32),
                        ("C", np.int32), ("slots", np.int32), ("apitch", np.int32),
-                       ("t0", np.int32), ("tile_begin", np.int32), ("reserved", np.int32)])
+                       ("t0", np.int32), ("tile_begin", np.int32), ("src_T", np.int16),
+                       ("src_t0", np.int16)])
 
     def __init__(self, device):
         self.device = device
@@ -366,14 +393,20 @@ class TransposePlan:
         self._table = None
         self._tiles = 0
 
-    def add(self, w: torch.Tensor, out: torch.Tensor, t0: int = 0) -> None:
+    def add(self, w: torch.Tensor, out: torch.Tensor, t0: int = 0, src_t0: int = 0,
+            ntaps: Optional[int] = None) -> None:
+        """out[c, t0 + t, a] = w[a, src_t0 + t, c] for t < ntaps (default: every tap of w)."""
         _need_gpu(w, out)
-        A, T, C = w.shape
+        A, Tsrc, C = w.shape
+        T = Tsrc - src_t0 if ntaps is None else ntaps
         if w.dtype != BF16 or out.dtype != BF16 or not w.is_contiguous() or not out.is_contiguous():
             raise ValueError("transpose operands must be contiguous bfloat16")
+        if T < 1 or src_t0 < 0 or src_t0 + T > Tsrc or Tsrc > 32767:
+            raise ValueError("transpose tap window out of range")
         if out.shape[0] != C or out.shape[1] < t0 + T or out.shape[2] < A:
             raise ValueError(f"transpose output {tuple(out.shape)} too small for {tuple(w.shape)}")
-        self._jobs.append((w.data_ptr(), out.data_ptr(), A, T, C, out.shape[1], out.shape[2], t0))
+        self._jobs.append((w.data_ptr(), out.data_ptr(), A, T, C, out.shape[1], out.shape[2], t0,
+                           Tsrc, src_t0))
         self._table = None
 
     def run(self) -> None:
@@ -382,8 +415,8 @@ class TransposePlan:
         if self._table is None:
             rec = np.zeros(len(self._jobs), dtype=self._DTYPE)
             tiles = 0
-            for i, (src, dst, A, T, C, slots, apitch, t0) in enumerate(self._jobs):
-                rec[i] = (src, dst, A, T, C, slots, apitch, t0, tiles, 0)
+            for i, (src, dst, A, T, C, slots, apitch, t0, Tsrc, st0) in enumerate(self._jobs):
+                rec[i] = (src, dst, A, T, C, slots, apitch, t0, tiles, Tsrc, st0)
                 tiles += T * ((A + 63) // 64) * ((C + 63) // 64)
             self._tiles = tiles
             self._table = torch.from_numpy(rec.view(np.uint8)).to(self.device)
@@ -391,6 +424,96 @@ class TransposePlan:
             check(lib().pe_transpose_weights_batched_bf16(
                 self._table.data_ptr(), len(self._jobs), self._tiles,
                 torch.cuda.current_stream(self.device).cuda_stream))
+
+
+_narrow_layouts: dict = {}
+
+
+def narrow_bwd_layout(k: int, stride: int, pad: int, cout: int):
+    """(slot_of_tap, sub_of_tap, nslots) of the backward-data weights of a k x k conv with 8, 16
+    or 32 output channels (see pe_conv2d_bwd_data_narrow_layout)."""
+    key = (k, stride, pad, cout)
+    if key not in _narrow_layouts:
+        slot = (ctypes.c_int32 * (k * k))()
+        sub = (ctypes.c_int32 * (k * k))()
+        n = ctypes.c_int32(0)
+        check(lib().pe_conv2d_bwd_data_narrow_layout(k, k, stride, pad, cout,
+                                                     ctypes.addressof(slot), ctypes.addressof(sub),
+                                                     ctypes.byref(n)))
+        _narrow_layouts[key] = (list(slot), list(sub), n.value)
+    return _narrow_layouts[key]
+
+
+def bwd_data_weight_shape(cin: int, cout: int, k: int, stride: int, pad: int):
+    """Shape of the re-packed weight conv2d_bwd_data reads."""
+    if cout in (8, 16, 32):
+        return (cin, narrow_bwd_layout(k, stride, pad, cout)[2], 64)
+    return (cin, k * k, cout)
+
+
+def plan_bwd_data_weight(plan: "TransposePlan", w_packed: torch.Tensor, w_t: torch.Tensor,
+                         cin: int, cout: int, k: int, stride: int, pad: int) -> None:
+    """Adds to `plan` the jobs that re-pack the forward weight of a k x k conv (regular
+    [Cout,k,k,Cin] or narrow [Cout,k,ceil(k/P),64] packing) into w_t (bwd_data_weight_shape,
+    zero-initialised by the caller: sub-blocks no tap maps to must stay zero)."""
+    if cin in (8, 16, 32):
+        Pin = 64 // cin
+        row = (k + Pin - 1) // Pin * Pin        # source taps per filter row, zero past k
+        src = w_packed.view(cout, k * row, cin)
+    else:
+        row = k
+        src = w_packed.view(cout, k * k, cin)
+    if cout in (8, 16, 32):
+        slot, sub, nslots = narrow_bwd_layout(k, stride, pad, cout)
+        P = 64 // cout
+        dst = w_t.view(cin, nslots * P, cout)
+        for kh in range(k):
+            for kw in range(k):
+                plan.add(src, dst, t0=slot[kh * k + kw] * P + sub[kh * k + kw],
+                         src_t0=kh * row + kw, ntaps=1)
+    else:
+        for kh in range(k):
+            plan.add(src, w_t, t0=kh * k, src_t0=kh * row, ntaps=k)
+
+
+def narrow_weight_mask(cout: int, cin: int, k: int) -> torch.Tensor:
+    """float32 [Cout,k,ceil(k/P),64]: 1 where the narrow packing holds a parameter, 0 on the
+    zero fill past the filter width."""
+    return pack_conv_weight_narrow(torch.ones(cout, cin, k, k)).float()
+
+
+def add_bf16(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """a + b for bf16 tensors of one shape (float32 sum, one rounding)."""
+    _need_gpu(a, b, out)
+    if a.shape != b.shape or a.dtype != BF16 or b.dtype != BF16 or not (a.is_contiguous() and b.is_contiguous()):
+        raise ValueError("add_bf16: contiguous bfloat16 tensors of one shape")
+    if out is None:
+        out = torch.empty_like(a)
+    with on_device(a):
+        check(lib().pe_add_bf16(a.data_ptr(), b.data_ptr(), a.numel(), out.data_ptr(), _stream(a)))
+    return out
+
+
+def fuse_upsample_add_bwd(dy: torch.Tensor, y: Optional[torch.Tensor], log2_factors,
+                          want_base: bool = True):
+    """Backward of fuse_upsample_add: returns (dbase, [dlow_i]).  y is the forward output when
+    the forward applied a ReLU, else None (then dbase is dy itself)."""
+    _check_act(dy, "dy")
+    B, H, W, C = dy.shape
+    if y is not None and (y.shape != dy.shape or y.dtype != BF16):
+        raise ValueError("y must match dy")
+    n = len(log2_factors)
+    dlows = [torch.empty((B, H >> f, W >> f, C), dtype=BF16, device=dy.device) for f in log2_factors]
+    dbase = torch.empty_like(dy) if (want_base and y is not None) else None
+    ptrs = (ctypes.c_void_p * max(n, 1))(*[t.data_ptr() for t in dlows])
+    facs = (ctypes.c_int32 * max(n, 1))(*[int(f) for f in log2_factors])
+    with on_device(dy):
+        check(lib().pe_fuse_upsample_add_bwd_bf16(dy.data_ptr(), _ptr(y), n, ctypes.addressof(ptrs),
+                                                  ctypes.addressof(facs), B, H, W, C, _ptr(dbase),
+                                                  _stream(dy)))
+    if want_base and y is None:
+        dbase = dy
+    return dbase, dlows
 
 
 def conv2d_bwd_data(dy: torch.Tensor, w_t: torch.Tensor, in_hw, k: int, stride: int, pad: int,
@@ -401,7 +524,11 @@ def conv2d_bwd_data(dy: torch.Tensor, w_t: torch.Tensor, in_hw, k: int, stride: 
     B, Ho, Wo, Cout = dy.shape
     Cin = w_t.shape[0]
     H, W = in_hw
-    if tuple(w_t.shape) != (Cin, k * k, Cout) or w_t.dtype != BF16:
+    if Cout in (8, 16, 32):
+        nslots = narrow_bwd_layout(k, stride, pad, Cout)[2]
+        if tuple(w_t.shape) != (Cin, nslots, 64) or w_t.dtype != BF16:
+            raise ValueError(f"narrow w_t must be bfloat16 [Cin, {nslots}, 64]")
+    elif tuple(w_t.shape) != (Cin, k * k, Cout) or w_t.dtype != BF16:
         raise ValueError("w_t must be bfloat16 [Cin, k*k, Cout]")
     if out is None:
         out = torch.empty((B, H, W, Cin), dtype=BF16, device=dy.device)
@@ -450,8 +577,10 @@ def conv2d_bwd_weight(x: torch.Tensor, dy: torch.Tensor, dw: torch.Tensor, k: in
     B, H, W, Cin = x.shape
     ldy = dy.shape[3]
     cout = ldy if cout is None else cout
-    if dw.dtype != torch.float32 or dw.numel() != cout * k * k * Cin or not dw.is_contiguous():
-        raise ValueError("dw must be contiguous float32 [Cout,k,k,Cin]")
+    elems = cout * k * ((k + 64 // Cin - 1) // (64 // Cin)) * 64 if Cin in (8, 16, 32) \
+        else cout * k * k * Cin
+    if dw.dtype != torch.float32 or dw.numel() != elems or not dw.is_contiguous():
+        raise ValueError("dw must be contiguous float32 in the forward weight's packed layout")
     d = ConvDesc(B, H, W, Cin, cout, k, k, stride, pad, 0, 0)
     with on_device(x):
         ws = wgrad_workspace(dw.numel(), x.device)
@@ -482,6 +611,22 @@ def stem7x7s2_bwd_weight(x_s2d: torch.Tensor, dy: torch.Tensor, dw: torch.Tensor
     with on_device(x_s2d):
         ws = wgrad_workspace(dw.numel(), x_s2d.device)
         check(lib().pe_stem7x7s2_bwd_weight_bf16(B, H2, W2, Cout, x_s2d.data_ptr(), dy.data_ptr(),
+                                                 dw.data_ptr(), ws.data_ptr(), ws.numel(),
+                                                 _stream(x_s2d)))
+
+
+def stem3x3s2_bwd_weight(x_s2d: torch.Tensor, dy: torch.Tensor, dw: torch.Tensor) -> None:
+    """dw (float32 [Cout,2,64], pre-zeroed) += weight gradient of the 3x3/2 stem; entries of the
+    packing that hold no parameter must be masked off by the caller."""
+    _check_act(x_s2d, "x_s2d")
+    _check_act(dy, "dy")
+    B, H2, W2, _ = x_s2d.shape
+    Cout = dy.shape[3]
+    if dw.dtype != torch.float32 or dw.numel() != Cout * 128:
+        raise ValueError("dw must be float32 [Cout,2,64]")
+    with on_device(x_s2d):
+        ws = wgrad_workspace(dw.numel(), x_s2d.device)
+        check(lib().pe_stem3x3s2_bwd_weight_bf16(B, H2, W2, Cout, x_s2d.data_ptr(), dy.data_ptr(),
                                                  dw.data_ptr(), ws.data_ptr(), ws.numel(),
                                                  _stream(x_s2d)))
 

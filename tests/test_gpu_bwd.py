@@ -334,3 +334,131 @@ def test_maxpool_backward_with_ties():
     assert idx.dtype == torch.uint8 and int(idx.max()) <= 8
     got = pnn.maxpool3x3s2_bwd(idx, dy.to(BF16).cuda())
     close(got.float().cpu(), nhwc(xt.grad), 4e-3)  # sums of up to 4 bf16 values, rounded once
+
+
+# ------------------------------------------------------------------ narrow channel counts
+def packed_fwd_weight(w_oihw):
+    cin = w_oihw.shape[1]
+    return (pnn.pack_conv_weight_narrow(w_oihw) if cin in (8, 16, 32)
+            else pnn.pack_conv_weight(w_oihw)).cuda()
+
+
+def planned_wt(w_oihw, k, s, p):
+    """Backward-data weights built from the forward packing through a TransposePlan."""
+    cout, cin = w_oihw.shape[:2]
+    wt = torch.zeros(pnn.bwd_data_weight_shape(cin, cout, k, s, p), dtype=BF16, device="cuda")
+    plan = pnn.TransposePlan(torch.device("cuda:0"))
+    wp = packed_fwd_weight(w_oihw)
+    pnn.plan_bwd_data_weight(plan, wp, wt, cin, cout, k, s, p)
+    plan.run()
+    torch.cuda.synchronize()
+    return wt
+
+
+NARROW_CASES = [
+    # B, H, W, Cin, Cout, k, stride, pad
+    (2, 16, 12, 32, 32, 3, 1, 1),
+    (3, 16, 12, 32, 32, 3, 2, 1),
+    (2, 17, 13, 32, 64, 3, 2, 1),     # odd map: ragged parity classes
+    (2, 16, 12, 64, 32, 1, 1, 0),
+    (2, 16, 12, 256, 32, 3, 1, 1),
+    (2, 8, 12, 32, 128, 3, 2, 1),
+    (2, 8, 6, 16, 16, 3, 1, 1),
+    (2, 8, 6, 32, 17, 1, 1, 0),       # head: 17 joints, gradient padded to 64 channels
+    (2, 16, 12, 128, 128, 3, 1, 1),   # regular on both sides, through the same plan
+]
+
+
+@pytest.mark.parametrize("case", NARROW_CASES)
+def test_narrow_conv_backward(case):
+    B, H, W, Cin, Cout, k, s, p = case
+    g = torch.Generator().manual_seed(71 + sum(case))
+    Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    x = ints((B, H, W, Cin), g, -2, 2)
+    dy = ints((B, Ho, Wo, Cout), g, -1, 1)
+    w = ints((Cout, Cin, k, k), g, -1, 1)
+    # backward-data (the 17-channel head pads its gradient and uses the regular path)
+    ref = nhwc(torch.nn.grad.conv2d_input((B, Cin, H, W), w, nchw(dy), stride=s, padding=p))
+    if Cout == 17:
+        dyp = torch.zeros(B, Ho, Wo, 64)
+        dyp[..., :17] = dy
+        wpad = torch.zeros(64, Cin, k, k)
+        wpad[:17] = w
+        got = pnn.conv2d_bwd_data(dyp.to(BF16).cuda(), planned_wt(wpad, k, s, p), (H, W), k, s, p)
+    else:
+        got = pnn.conv2d_bwd_data(dy.to(BF16).cuda(), planned_wt(w, k, s, p), (H, W), k, s, p)
+        dyp = dy
+    assert torch.equal(got.float().cpu(), to.bf16r(ref))
+    if not (k == 1 and s == 2) and Cout != 17:
+        res = ints((B, H, W, Cin), g, -3, 3)
+        got = pnn.conv2d_bwd_data(dy.to(BF16).cuda(), planned_wt(w, k, s, p), (H, W), k, s, p,
+                                  residual=res.to(BF16).cuda())
+        assert torch.equal(got.float().cpu(), to.bf16r(ref + res))
+    # backward-weight, in the forward weight's own packing
+    refw = torch.nn.grad.conv2d_weight(nchw(x), (Cout, Cin, k, k), nchw(dy), stride=s, padding=p)
+    wp = packed_fwd_weight(w)
+    dw = torch.zeros(wp.shape, device="cuda")
+    pnn.conv2d_bwd_weight(x.to(BF16).cuda(), dyp.to(BF16).cuda(), dw, k, s, p, cout=Cout)
+    if Cin in (8, 16, 32):
+        expect = pnn.pack_conv_weight_narrow(refw).float()
+        got = dw.cpu() * pnn.narrow_weight_mask(Cout, Cin, k)
+    else:
+        expect = pnn.pack_conv_weight(refw).float()
+        got = dw.cpu()
+    assert torch.equal(got, expect)
+    # forward with fused statistics on the narrow packing stores the plain conv's output
+    if Cout % 8 == 0:
+        ws = pnn.bn_workspace(B * Ho * Wo, Cout, "cuda")
+        kw = {"kw": k} if Cin in (8, 16, 32) else {}
+        z, rows = pnn.conv2d_bnstats(x.to(BF16).cuda(), wp.to(BF16), ws, s, p, **kw)
+        refz = nhwc(F.conv2d(nchw(x), w, None, stride=s, padding=p))
+        assert torch.equal(z.float().cpu(), to.bf16r(refz))
+        assert rows >= 1
+
+
+def test_stem3x3_training_entries():
+    g = torch.Generator().manual_seed(83)
+    B, H, W, Cout = 2, 32, 24, 64
+    x3 = ints((B, H, W, 3), g, -2, 2)
+    w = ints((Cout, 3, 3, 3), g, -1, 1)
+    dy = ints((B, H // 2, W // 2, Cout), g, -1, 1)
+    xs = torch.from_numpy(to.space_to_depth16(x3.numpy())).to(BF16).cuda()
+    wp = pnn.pack_stem3x3_weight(w).cuda()
+    ws = pnn.bn_workspace(B * (H // 2) * (W // 2), Cout, "cuda")
+    z, rows = pnn.stem3x3s2_bnstats(xs, wp, ws)
+    refz = nhwc(F.conv2d(nchw(x3), w, None, stride=2, padding=1))
+    assert torch.equal(z.float().cpu(), to.bf16r(refz)) and rows >= 1
+    gamma, beta = torch.ones(Cout, device="cuda"), torch.zeros(Cout, device="cuda")
+    mean = pnn.bn_finalize(ws, rows, z.numel() // Cout, Cout, gamma, beta, 1e-5, 0.1, None, None)[0]
+    assert torch.allclose(mean.cpu(), refz.mean(dim=(0, 1, 2)), atol=1e-5)
+    ref = torch.nn.grad.conv2d_weight(nchw(x3), (Cout, 3, 3, 3), nchw(dy), stride=2, padding=1)
+    dw = torch.zeros(Cout, 2, 64, device="cuda")
+    pnn.stem3x3s2_bwd_weight(xs, dy.to(BF16).cuda(), dw)
+    mask = pnn.pack_stem3x3_weight(torch.ones(Cout, 3, 3, 3)).float()
+    assert torch.equal(dw.cpu() * mask, pnn.pack_stem3x3_weight(ref).float())
+
+
+@pytest.mark.parametrize("relu", [True, False])
+def test_fuse_upsample_add_backward(relu):
+    g = torch.Generator().manual_seed(89)
+    B, H, W, C = 2, 16, 8, 32
+    base = rnd((B, H, W, C), g)
+    lows = [rnd((B, H >> f, W >> f, C), g) for f in (1, 2, 3)]
+    dy = rnd((B, H, W, C), g)
+    tb = nchw(base).requires_grad_(True)
+    tl = [nchw(t).requires_grad_(True) for t in lows]
+    s = tb
+    for t, f in zip(tl, (1, 2, 3)):
+        s = s + t.repeat_interleave(1 << f, dim=2).repeat_interleave(1 << f, dim=3)
+    y = pnn.fuse_upsample_add(base.to(BF16).cuda(), [t.to(BF16).cuda() for t in lows], [1, 2, 3],
+                              relu=relu)
+    # mask with the kernel's own (bf16-rounded) output, as the training graph does
+    yf = nchw(y.float().cpu())
+    out = s * (yf > 0).float() if relu else s
+    out.backward(nchw(dy))
+    dbase, dlows = pnn.fuse_upsample_add_bwd(dy.to(BF16).cuda(), y if relu else None, [1, 2, 3])
+    assert torch.equal(dbase.float().cpu(), to.bf16r(nhwc(tb.grad)))
+    for got, t in zip(dlows, tl):
+        close(got.float().cpu(), nhwc(t.grad), 4e-3)
+    a, b = rnd((3, 5, 7, 8), g), rnd((3, 5, 7, 8), g)
+    assert torch.equal(pnn.add_bf16(a.to(BF16).cuda(), b.to(BF16).cuda()).float().cpu(), to.bf16r(a + b))
