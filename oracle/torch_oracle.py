@@ -371,3 +371,117 @@ def pose_resnet_train_reference(specs, state, img_u8, targets, weights, mask, me
     loss = 0.5 * e.mean()
     loss.backward()
     return loss.item(), hm.detach(), {k: p.grad for k, p in P.items()}
+
+
+def _hrnet_module_autograd(m, xs, unit, rb):
+    """One exchange module (branches, then fusion) in NCHW autograd tensors."""
+    def up(t, f):
+        return t.repeat_interleave(1 << f, dim=2).repeat_interleave(1 << f, dim=3)
+
+    ys = []
+    for x, br in zip(xs, m.branches):
+        for blk in br:
+            x = unit(blk.c2, unit(blk.c1, x), residual=x, relu=True)
+        ys.append(x)
+    outs = []
+    for i, row in enumerate(m.fuse):
+        lows = [j for j in range(len(row)) if j > i]
+        s = ys[i]
+        for j in range(i):
+            t = ys[j]
+            for u in row[j][:-1]:
+                t = unit(u, t)
+            s = unit(row[j][-1], t, residual=s, relu=(j == i - 1 and not lows))
+        if lows:
+            for j in lows:
+                s = s + up(unit(row[j][0], ys[j]), j - i)
+            s = rb(torch.relu(s))
+        outs.append(s)
+    return outs
+
+
+def hrnet_module_train_reference(m, state, xs_nhwc, douts_nhwc, bn_eps: float = 1e-5):
+    """Forward (batch statistics) + autograd backward of ONE exchange module on the CPU with
+    bf16 rounding at the kernels' storage points.  xs / douts: float32 NHWC lists (one per
+    branch / per fusion output) holding bf16 values.
+    Returns ([out NHWC], [dx NHWC], {name: grad in framework layout})."""
+    rb, rw = _RoundBoth.apply, _RoundFwd.apply
+    P = {}
+
+    def unit(u, x, residual=None, relu=None):
+        for nm in (".weight", ".bn.gamma", ".bn.beta"):
+            if u.name + nm not in P:
+                P[u.name + nm] = state[u.name + nm].clone().float().requires_grad_(True)
+        z = rb(F.conv2d(x, rw(P[u.name + ".weight"]), None, stride=u.stride, padding=u.k // 2))
+        y = F.batch_norm(z, None, None, P[u.name + ".bn.gamma"], P[u.name + ".bn.beta"],
+                         training=True, momentum=0.0, eps=bn_eps)
+        if residual is not None:
+            y = y + residual
+        if u.relu if relu is None else relu:
+            y = torch.relu(y)
+        return rb(y)
+
+    xs = [_nchw(x).requires_grad_(True) for x in xs_nhwc]
+    outs = _hrnet_module_autograd(m, xs, unit, rb)
+    torch.autograd.backward(outs, [_nchw(d) for d in douts_nhwc])
+    return ([_nhwc(o.detach()) for o in outs], [_nhwc(x.grad) for x in xs],
+            {k: p.grad for k, p in P.items()})
+
+
+def hrnet_train_reference(spec, state, img_u8, targets, weights, mask, mean, std,
+                          bn_eps: float = 1e-5, round_bf16: bool = True, x_nhwc=None,
+                          dout_nchw=None):
+    """One forward/backward of the HRNet-style training graph on the CPU with torch autograd:
+    batch-statistics BN after every conv, the same branch / exchange wiring as
+    hrnet_pose_forward, bf16 rounding (round_bf16) where the kernels store bf16 (weights, conv
+    outputs, activations, fusion outputs and the gradients of all of those).
+
+    Default: image -> heat maps -> masked MSE (as pose_resnet_train_reference); returns
+    (loss, heatmaps, {name: grad}).  With x_nhwc and dout_nchw given, the stem is skipped: the
+    graph starts at layer1 from x_nhwc and the heat maps are seeded with dout_nchw instead of a
+    loss (loss is returned as 0)."""
+    rb = _RoundBoth.apply if round_bf16 else (lambda t: t)
+    rw = _RoundFwd.apply if round_bf16 else (lambda t: t)
+    P = {}
+    for k, v in state.items():
+        if k.endswith(".bn.mean") or k.endswith(".bn.var"):
+            continue
+        P[k] = v.clone().float().requires_grad_(True)
+
+    def unit(u, x, residual=None, relu=None):
+        z = rb(F.conv2d(x, rw(P[u.name + ".weight"]), None, stride=u.stride, padding=u.k // 2))
+        y = F.batch_norm(z, None, None, P[u.name + ".bn.gamma"], P[u.name + ".bn.beta"],
+                         training=True, momentum=0.0, eps=bn_eps)
+        if residual is not None:
+            y = y + residual
+        if u.relu if relu is None else relu:
+            y = torch.relu(y)
+        return rb(y)
+
+    if x_nhwc is None:
+        x = torch.from_numpy(preprocess_u8(img_u8, mean, std)).permute(0, 3, 1, 2).contiguous()
+        for u in spec.stem:
+            x = unit(u, x)
+    else:
+        x = _nchw(x_nhwc)
+    for b in spec.layer1:
+        idn = unit(b.down, x) if b.down else x
+        x = unit(b.c3, unit(b.c2, unit(b.c1, x)), residual=idn, relu=True)
+    xs = [x]
+    for tr, mods in zip(spec.transitions, spec.stages):
+        xs = [(xs[i] if t is None else unit(t, xs[i])) if i < len(xs) else unit(t, xs[-1])
+              for i, t in enumerate(tr)]
+        for m in mods:
+            xs = _hrnet_module_autograd(m, xs, unit, rb)
+    hm = F.conv2d(xs[0], rw(P["final.weight"]), P["final.bias"])
+    if dout_nchw is not None:
+        hm.backward(dout_nchw)
+        return 0.0, hm.detach(), {k: p.grad for k, p in P.items()}
+    t = torch.as_tensor(targets)
+    w = torch.as_tensor(weights)[:, :, None, None]
+    e = (w * (hm - t)) ** 2
+    if mask is not None:
+        e = e * torch.as_tensor(mask).bool()[:, None].float()
+    loss = 0.5 * e.mean()
+    loss.backward()
+    return loss.item(), hm.detach(), {k: p.grad for k, p in P.items()}

@@ -1,0 +1,407 @@
+"""Training graphs on the HIP kernels for networks that are not a plain chain of blocks
+(multi-branch, multi-head): parameters in flat arenas, forward layers that record what their
+backward needs on a tape, a reverse sweep that accumulates activation gradients, bucketed
+data-parallel gradient exchange and the fused optimizer.
+
+The reference's training code (train.py, model/base_model.py; PoseEstimation.pyproj:30,34) is
+absent; what is visible is `Trainer(config)`, Adam(0.9, 0.999, 1e-8) with exponential decay
+(test.ipynb:400, 1001-1008) and Horovod-style data parallelism (test.ipynb:12): local batch
+statistics, summed gradients averaged over ranks.
+
+A layer is conv + batch norm (+ residual) (+ ReLU / ReLU6), or a head (1x1 conv + bias to
+float32 NCHW maps).  In training mode every layer is
+    conv with fused batch statistics -> finalize -> normalise/residual/activation
+and pushes (input, pre-norm output, output) on the tape; backward pops the tape: batch-norm
+backward, weight gradient on a side stream, backward-data into the input's gradient (added to
+what other consumers already left there).  In inference mode the same graph code runs the
+folded-BN kernels and records nothing.
+"""
+from __future__ import annotations
+
+from contextlib import contextmanager
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import nn as pnn
+from . import ops
+from .parallel import GradBucketer
+
+BF16 = torch.bfloat16
+BN_EPS = 1e-5
+HEAD_KPAD = 64   # a head's loss gradient is zero-padded to this many channels for the MFMA passes
+NARROW = (8, 16, 32)
+
+
+@dataclass
+class Layer:
+    name: str
+    kind: str            # "conv" | "stem3" (3x3/2 on the space-to-depth image) | "head"
+    cin: int
+    cout: int
+    k: int = 1
+    stride: int = 1
+    relu: int = 1        # activation after BN (+ residual): 0 none, 1 ReLU, 2 ReLU6
+
+    @property
+    def pad(self) -> int:
+        return self.k // 2
+
+    @property
+    def narrow(self) -> bool:
+        return self.kind != "stem3" and self.cin in NARROW
+
+    def packed_shape(self) -> Tuple[int, ...]:
+        if self.kind == "stem3":
+            return (self.cout, 2, 64)
+        if self.narrow:
+            P = 64 // self.cin
+            return (self.cout, self.k, (self.k + P - 1) // P, 64)
+        return (self.cout, self.k, self.k, self.cin)
+
+    def pack(self, w_oihw: torch.Tensor) -> torch.Tensor:
+        """Framework-layout float32 weight -> packed layout, still float32."""
+        w = w_oihw.float()
+        if self.kind == "stem3":
+            return pnn.pack_stem3x3_weight(w, torch.float32)
+        if self.narrow:
+            return pnn.pack_conv_weight_narrow(w, torch.float32)
+        return pnn.pack_conv_weight(w, torch.float32)
+
+    def param_mask(self) -> Optional[torch.Tensor]:
+        """1 where the packed layout holds a parameter, None when it is dense."""
+        if self.kind == "stem3" or self.narrow:
+            return self.pack(torch.ones(self.cout, 3 if self.kind == "stem3" else self.cin,
+                                        self.k, self.k))
+        return None
+
+
+class Var:
+    """An activation and, during backward, the gradient accumulated for it so far."""
+    __slots__ = ("t", "grad", "needs_grad")
+
+    def __init__(self, t: torch.Tensor, needs_grad: bool = True):
+        self.t = t
+        self.grad: Optional[torch.Tensor] = None
+        self.needs_grad = needs_grad
+
+
+def _align8(n: int) -> int:
+    return (n + 7) // 8 * 8
+
+
+class TrainGraph:
+    """Parameter arenas + tape for a list of layers given in forward execution order."""
+
+    def __init__(self, device, layers: Sequence[Layer], bn_momentum: float = 0.1):
+        self.device = torch.device(device)
+        self.layers: List[Layer] = list(layers)
+        self.by_name: Dict[str, Layer] = {L.name: L for L in self.layers}
+        if len(self.by_name) != len(self.layers):
+            raise ValueError("layer names must be unique")
+        self.bn_momentum = bn_momentum
+        dev = self.device
+        # ---- arena layout: every tensor starts on an 8-element boundary
+        self.offsets: Dict[str, Tuple[int, Tuple[int, ...]]] = {}
+        self.layer_starts: List[int] = []
+        off = 0
+        for L in self.layers:
+            self.layer_starts.append(off)
+            shp = L.packed_shape()
+            n = 1
+            for s in shp:
+                n *= s
+            self.offsets[L.name + ".weight"] = (off, shp)
+            off += _align8(n)
+            for nm in ((".bias",) if L.kind == "head" else (".bn.gamma", ".bn.beta")):
+                self.offsets[L.name + nm] = (off, (L.cout,))
+                off += _align8(L.cout)
+        self.n_params = off
+        self._views: Dict[tuple, torch.Tensor] = {}
+        self.master = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.work = torch.zeros(off, dtype=BF16, device=dev)
+        self.grads = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.opt_m = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.opt_v = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.step_count = 0
+        bn_layers = [L for L in self.layers if L.kind != "head"]
+        self.bn_mean = {L.name: torch.zeros(L.cout, device=dev) for L in bn_layers}
+        self.bn_var = {L.name: torch.ones(L.cout, device=dev) for L in bn_layers}
+        self.bn_buf = {L.name: torch.empty(4, L.cout, dtype=torch.float32, device=dev)
+                       for L in bn_layers}
+        self.bn_rows = {k: tuple(v.unbind(0)) for k, v in self.bn_buf.items()}
+        self.scale: Dict[str, torch.Tensor] = {}
+        self.shift: Dict[str, torch.Tensor] = {}
+        # re-packed weights for the backward-data passes (the stem has none: images need no gradient)
+        self.wt: Dict[str, torch.Tensor] = {}
+        self.masks: Dict[str, torch.Tensor] = {}
+        for L in self.layers:
+            if L.kind == "conv":
+                shp = pnn.bwd_data_weight_shape(L.cin, L.cout, L.k, L.stride, L.pad)
+                self.wt[L.name] = torch.zeros(shp, dtype=BF16, device=dev)
+            elif L.kind == "head":
+                self.wt[L.name] = torch.zeros(L.cin, 1, HEAD_KPAD, dtype=BF16, device=dev)
+            m = L.param_mask()
+            if m is not None:
+                self.masks[L.name] = m.to(dev)
+        self._tplan: Optional[pnn.TransposePlan] = None
+        self._ws: Optional[torch.Tensor] = None
+        self.tape: list = []
+        self.training = False
+        self.bucketer: Optional[GradBucketer] = None
+        self._done_names: set = set()
+        self._next_layer = len(self.layers) - 1
+        # weight gradients depend only on a layer's input and its output gradient and nothing
+        # reads them before the optimizer: they run beside the backward-data chain
+        self.wgrad_stream: Optional[torch.cuda.Stream] = torch.cuda.Stream(device=dev)
+
+    # ------------------------------------------------------------------ parameters
+    def view(self, arena: torch.Tensor, name: str) -> torch.Tensor:
+        key = (arena.data_ptr(), arena.dtype, name)
+        v = self._views.get(key)
+        if v is None:
+            off, shp = self.offsets[name]
+            n = 1
+            for s in shp:
+                n *= s
+            v = arena[off:off + n].view(shp)
+            self._views[key] = v
+        return v
+
+    def w(self, L: Layer) -> torch.Tensor:
+        return self.view(self.work, L.name + ".weight")
+
+    def _g(self, name: str) -> torch.Tensor:
+        return self.view(self.grads, name)
+
+    def load_state(self, state: Dict[str, torch.Tensor]) -> None:
+        """Framework-layout state dict ([Cout,Cin,k,k] weights, .bn.gamma/.bn.beta/.bn.mean/
+        .bn.var vectors, .bias for heads) -> arenas."""
+        for L in self.layers:
+            self.view(self.master, L.name + ".weight").copy_(
+                L.pack(state[L.name + ".weight"]).to(self.device))
+            if L.kind == "head":
+                self.view(self.master, L.name + ".bias").copy_(state[L.name + ".bias"])
+            else:
+                self.view(self.master, L.name + ".bn.gamma").copy_(state[L.name + ".bn.gamma"])
+                self.view(self.master, L.name + ".bn.beta").copy_(state[L.name + ".bn.beta"])
+                self.bn_mean[L.name].copy_(state[L.name + ".bn.mean"])
+                self.bn_var[L.name].copy_(state[L.name + ".bn.var"])
+        self.work.copy_(self.master)  # one rounding to bf16
+        self.fold_bn()
+        self.refresh_transposes()
+
+    def fold_bn(self) -> None:
+        """Inference epilogue constants from the running statistics."""
+        for L in self.layers:
+            if L.kind == "head":
+                continue
+            gamma = self.view(self.master, L.name + ".bn.gamma")
+            beta = self.view(self.master, L.name + ".bn.beta")
+            sc = gamma / torch.sqrt(self.bn_var[L.name] + BN_EPS)
+            self.scale[L.name] = sc.contiguous()
+            self.shift[L.name] = (beta - self.bn_mean[L.name] * sc).contiguous()
+
+    def refresh_transposes(self) -> None:
+        """Re-packs every weight for the backward-data GEMMs (one launch for all layers)."""
+        if self._tplan is None:
+            plan = pnn.TransposePlan(self.device)
+            for L in self.layers:
+                if L.kind == "conv":
+                    pnn.plan_bwd_data_weight(plan, self.w(L), self.wt[L.name], L.cin, L.cout, L.k,
+                                             L.stride, L.pad)
+                elif L.kind == "head":
+                    pnn.plan_bwd_data_weight(plan, self.w(L), self.wt[L.name], L.cin, L.cout, 1, 1, 0)
+            self._tplan = plan
+        self._tplan.run()
+
+    def enable_data_parallel(self, bucket_bytes: int = 32 << 20, group=None) -> None:
+        """Call after torch.distributed is initialised; parameters must already be identical on
+        every rank (same seed / same loaded state, or broadcast_parameters())."""
+        self.bucketer = GradBucketer(self.grads, self.layer_starts, bucket_bytes, group)
+
+    def broadcast_parameters(self, src: int = 0) -> None:
+        import torch.distributed as dist
+
+        dist.broadcast(self.master, src)
+        for t in list(self.bn_mean.values()) + list(self.bn_var.values()):
+            dist.broadcast(t, src)
+        self.work.copy_(self.master)
+        self.refresh_transposes()
+
+    def _workspace_for(self, M: int, C: int) -> torch.Tensor:
+        need = pnn.lib().pe_bn_workspace_bytes(M, C)
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(max(need, 1 << 24), dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    # ------------------------------------------------------------------ forward layers
+    def begin(self, training: bool) -> None:
+        self.training = training
+        self.tape = []
+
+    def unit(self, L: Layer, x: Var, residual: Optional[Var] = None,
+             relu: Optional[int] = None) -> Var:
+        """act( bn(conv(x)) + residual ); `relu` overrides the layer's own activation."""
+        act = L.relu if relu is None else int(relu)
+        kw = {"kw": L.k} if L.narrow else {}
+        res_t = residual.t if residual is not None else None
+        if not self.training:
+            if L.kind == "stem3":
+                y = pnn.stem3x3s2(x.t, self.w(L), self.scale[L.name], self.shift[L.name], relu=act)
+            else:
+                y = pnn.conv2d(x.t, self.w(L), self.scale[L.name], self.shift[L.name], res_t,
+                               L.stride, L.pad, act, **kw)
+            return Var(y, False)
+        B, H, W, _ = x.t.shape
+        if L.kind == "stem3":
+            M = B * H * W
+            z, rows = pnn.stem3x3s2_bnstats(x.t, self.w(L), self._workspace_for(M, L.cout))
+        else:
+            Ho = (H + 2 * L.pad - L.k) // L.stride + 1
+            Wo = (W + 2 * L.pad - L.k) // L.stride + 1
+            M = B * Ho * Wo
+            z, rows = pnn.conv2d_bnstats(x.t, self.w(L), self._workspace_for(M, L.cout), L.stride,
+                                         L.pad, **kw)
+        _, _, scale, shift = pnn.bn_finalize(
+            self._ws, rows, M, L.cout, self.view(self.master, L.name + ".bn.gamma"),
+            self.view(self.master, L.name + ".bn.beta"), BN_EPS, self.bn_momentum,
+            self.bn_mean[L.name], self.bn_var[L.name], out=self.bn_rows[L.name])
+        out = Var(pnn.bn_apply(z, scale, shift, res_t, act))
+        self.tape.append(("unit", L, x, residual, act, z, out))
+        return out
+
+    def fuse(self, base: Var, lows: Sequence[Var], log2_factors: Sequence[int],
+             relu: bool = True) -> Var:
+        """relu?( base + sum of nearest-upsampled lows )."""
+        y = pnn.fuse_upsample_add(base.t, [v.t for v in lows], list(log2_factors), relu=relu)
+        out = Var(y, self.training)
+        if self.training:
+            self.tape.append(("fuse", base, list(lows), list(log2_factors), relu, out))
+        return out
+
+    def head(self, L: Layer, x: Var) -> torch.Tensor:
+        """1x1 conv + bias to float32 NCHW maps."""
+        kw = {"kw": 1} if L.narrow else {}
+        y = pnn.conv2d(x.t, self.w(L), None, self.view(self.master, L.name + ".bias"),
+                       out_f32_nchw=True, **kw)
+        if self.training:
+            self.tape.append(("head", L, x))
+        return y
+
+    # ------------------------------------------------------------------ backward
+    @contextmanager
+    def _beside(self, *tensors: torch.Tensor):
+        """Launches inside run on the weight-gradient stream, after everything queued on the
+        current stream so far.  `tensors` are what those launches read: the caching allocator is
+        told not to hand their memory out again before the side stream is done with it."""
+        side = self.wgrad_stream
+        if side is None:
+            yield
+            return
+        side.wait_stream(torch.cuda.current_stream(self.device))
+        for t in tensors:
+            t.record_stream(side)
+        with torch.cuda.stream(side):
+            yield
+
+    def _done(self, L: Layer) -> None:
+        """Marks a layer's gradients as enqueued.  Buckets are announced in descending arena
+        order whatever order a branched graph finishes its layers in."""
+        if self.bucketer is None:
+            return
+        self._done_names.add(L.name)
+        while self._next_layer >= 0 and self.layers[self._next_layer].name in self._done_names:
+            self.bucketer.layer_done(self.layer_starts[self._next_layer])
+            self._next_layer -= 1
+
+    def _acc(self, v: Var, g: torch.Tensor) -> None:
+        if not v.needs_grad:
+            return
+        v.grad = g if v.grad is None else pnn.add_bf16(v.grad, g)
+
+    def _weight_grad(self, L: Layer, x: torch.Tensor, dz: torch.Tensor, cout=None) -> None:
+        gw = self._g(L.name + ".weight")
+        with self._beside(x, dz):
+            if L.kind == "stem3":
+                pnn.stem3x3s2_bwd_weight(x, dz, gw)
+            else:
+                pnn.conv2d_bwd_weight(x, dz, gw, L.k, L.stride, L.pad, cout=cout)
+            m = self.masks.get(L.name)
+            if m is not None:
+                pnn.mul_(gw, m)
+            self._done(L)
+
+    def _data_grad(self, L: Layer, x: Var, dz: torch.Tensor) -> None:
+        if not x.needs_grad:
+            return
+        hw = tuple(x.t.shape[1:3])
+        fused = x.grad is not None and not (L.k == 1 and L.stride == 2)
+        dx = pnn.conv2d_bwd_data(dz, self.wt[L.name], hw, L.k, L.stride, L.pad,
+                                 residual=x.grad if fused else None)
+        if x.grad is not None and not fused:
+            dx = pnn.add_bf16(x.grad, dx)
+        x.grad = dx
+
+    def backward(self, head_grads: Dict[str, torch.Tensor]) -> None:
+        """head_grads: {head layer name: float32 [B,K,H,W] dLoss/dMaps}.  Fills self.grads."""
+        self.grads.zero_()
+        self._done_names = set()
+        self._next_layer = len(self.layers) - 1
+        while self.tape:
+            rec = self.tape.pop()
+            if rec[0] == "head":
+                _, L, x = rec
+                dyp = pnn.final_grad_prepare(head_grads[L.name], HEAD_KPAD, self._g(L.name + ".bias"))
+                self._weight_grad(L, x.t, dyp, cout=L.cout)
+                if x.needs_grad:
+                    hw = tuple(x.t.shape[1:3])
+                    x.grad = pnn.conv2d_bwd_data(dyp, self.wt[L.name], hw, 1, 1, 0,
+                                                 residual=x.grad)
+            elif rec[0] == "fuse":
+                _, base, lows, facs, relu, out = rec
+                if out.grad is None:
+                    raise RuntimeError("a fusion output received no gradient")
+                dbase, dlows = pnn.fuse_upsample_add_bwd(out.grad, out.t if relu else None, facs)
+                self._acc(base, dbase)
+                for v, g in zip(lows, dlows):
+                    self._acc(v, g)
+                out.grad = None
+            else:
+                _, L, x, residual, act, z, out = rec
+                if out.grad is None:
+                    raise RuntimeError(f"layer {L.name}: output received no gradient")
+                buf = self.bn_rows[L.name]
+                masked = residual is not None and act != 0
+                dz, g = pnn.bn_bwd(out.grad, out.t if act else None, z,
+                                   self.view(self.master, L.name + ".bn.gamma"), buf[0], buf[1],
+                                   self._g(L.name + ".bn.gamma"), self._g(L.name + ".bn.beta"),
+                                   self._workspace_for(z.numel() // L.cout, L.cout), masked,
+                                   relu=act or 1)
+                if residual is not None:
+                    self._acc(residual, g if masked else out.grad)
+                self._weight_grad(L, x.t, dz)
+                if L.kind != "stem3":
+                    self._data_grad(L, x, dz)
+                out.grad = None
+        if self.wgrad_stream is not None:   # the optimizer reads every gradient
+            torch.cuda.current_stream(self.device).wait_stream(self.wgrad_stream)
+
+    # ------------------------------------------------------------------ optimizer
+    def optimizer_step(self, lr: float, optimizer: str = "adam", beta1: float = 0.9,
+                       beta2: float = 0.999, eps: float = 1e-8, momentum: float = 0.9) -> None:
+        scale = 1.0
+        if self.bucketer is not None:
+            self.bucketer.finish()
+            scale = self.bucketer.grad_scale
+        self.step_count += 1
+        if optimizer == "adam":
+            ops.adam_step(self.master, self.opt_m, self.opt_v, self.grads, self.step_count, lr,
+                          beta1, beta2, eps, p_bf16=self.work, tf1=True, grad_scale=scale)
+        elif optimizer == "sgd":
+            ops.sgd_step(self.master, self.opt_m, self.grads, lr, momentum, p_bf16=self.work,
+                         grad_scale=scale)
+        else:
+            raise ValueError(f"unknown optimizer {optimizer!r}")
+        self.refresh_transposes()

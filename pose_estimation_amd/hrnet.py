@@ -28,6 +28,7 @@ import torch
 
 from . import nn as pnn
 from . import ops
+from .graph import Layer, TrainGraph, Var
 
 BF16 = torch.bfloat16
 BN_EPS = 1e-5
@@ -290,3 +291,97 @@ class PoseHRNet:
 
     def decode(self, heatmaps: torch.Tensor):
         return ops.decode(heatmaps)
+
+
+# --------------------------------------------------------------------------------------------
+# Training (and inference from the same arenas) on the tape-based graph
+# --------------------------------------------------------------------------------------------
+def _graph_layers(spec: HRNetSpec):
+    layers = []
+    for u in all_units(spec):
+        kind = "stem3" if u.name == "stem.conv1" else "conv"
+        layers.append(Layer(u.name, kind, u.cin, u.cout, u.k, u.stride, 1 if u.relu else 0))
+    layers.append(Layer("final", "head", spec.widths[0], spec.num_joints, 1, 1, 0))
+    return layers
+
+
+class TrainablePoseHRNet(TrainGraph):
+    """HRNet-W32-style pose network with its parameter arenas on one GPU: forward with batch
+    statistics, fused target-render + masked-MSE loss, backward through the branches and
+    exchange modules, fused optimizer; `predict` runs the same graph with folded BN."""
+
+    def __init__(self, device, num_joints: int = 17, width: int = 32, modules=(1, 4, 3),
+                 blocks: int = 4, layer1_blocks: int = 4, bn_momentum: float = 0.1,
+                 sigma: float = 3.0, heatmap_stride: float = 4.0):
+        self.spec = hrnet_specs(num_joints, width, modules, blocks, layer1_blocks)
+        super().__init__(device, _graph_layers(self.spec), bn_momentum)
+        self.num_joints = num_joints
+        self.sigma = sigma
+        self.radius = int(round(3 * sigma))
+        self.heatmap_stride = heatmap_stride
+
+    def _u(self, u: Unit, x, residual=None, relu=None):
+        return self.unit(self.by_name[u.name], x, residual,
+                         None if relu is None else (1 if relu else 0))
+
+    def _module(self, m: Module, xs):
+        ys = []
+        for x, br in zip(xs, m.branches):
+            for blk in br:
+                x = self._u(blk.c2, self._u(blk.c1, x), residual=x, relu=True)
+            ys.append(x)
+        outs = []
+        for i, row in enumerate(m.fuse):
+            lows = [(j, row[j]) for j in range(len(row)) if j > i]
+            s = ys[i]
+            for j in range(i):
+                t = ys[j]
+                chain = row[j]
+                for u in chain[:-1]:
+                    t = self._u(u, t)
+                s = self._u(chain[-1], t, residual=s, relu=(j == i - 1 and not lows))
+            if lows:
+                proj = [self._u(chain[0], ys[j]) for j, chain in lows]
+                s = self.fuse(s, proj, [j - i for j, _ in lows], relu=True)
+            outs.append(s)
+        return outs
+
+    def forward(self, x_s2d: torch.Tensor, training: bool) -> torch.Tensor:
+        """Space-to-depth image -> float32 heat maps [B,K,H/4,W/4]."""
+        sp = self.spec
+        self.begin(training)
+        x = Var(x_s2d, False)
+        x = self._u(sp.stem[0], x)
+        x = self._u(sp.stem[1], x)
+        for b in sp.layer1:
+            idn = self._u(b.down, x) if b.down else x
+            x = self._u(b.c3, self._u(b.c2, self._u(b.c1, x)), residual=idn, relu=True)
+        xs = [x]
+        for tr, mods in zip(sp.transitions, sp.stages):
+            xs = [(xs[i] if t is None else self._u(t, xs[i])) if i < len(xs)
+                  else self._u(t, xs[-1]) for i, t in enumerate(tr)]
+            for m in mods:
+                xs = self._module(m, xs)
+        return self.head(self.by_name["final"], xs[0])
+
+    def forward_train(self, images_u8: Optional[torch.Tensor],
+                      x_s2d: Optional[torch.Tensor] = None) -> torch.Tensor:
+        return self.forward(x_s2d if x_s2d is not None else pnn.preprocess_u8(images_u8), True)
+
+    def predict(self, images_u8: torch.Tensor) -> torch.Tensor:
+        """uint8 [B,H,W,3] -> float32 heat maps (running BN statistics; call fold_bn() after
+        training steps)."""
+        return self.forward(pnn.preprocess_u8(images_u8), False)
+
+    def train_step(self, images_u8, joints: torch.Tensor, mask: Optional[torch.Tensor] = None,
+                   lr: float = 1e-3, optimizer: str = "adam", beta1: float = 0.9,
+                   beta2: float = 0.999, eps: float = 1e-8, momentum: float = 0.9,
+                   x_s2d: Optional[torch.Tensor] = None):
+        """One optimisation step; returns (loss [1] device tensor, per_joint [K])."""
+        hm = self.forward_train(images_u8, x_s2d)
+        loss, per_joint, grad, _ = ops.mse_fwd_bwd(hm, joints=joints, mask=mask,
+                                                  stride=self.heatmap_stride, sigma=self.sigma,
+                                                  radius=self.radius)
+        self.backward({"final": grad})
+        self.optimizer_step(lr, optimizer, beta1, beta2, eps, momentum)
+        return loss, per_joint

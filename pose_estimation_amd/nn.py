@@ -20,13 +20,13 @@ BF16 = torch.bfloat16
 
 
 # --------------------------------------------------------------------------- packers
-def pack_conv_weight(w_oihw: torch.Tensor) -> torch.Tensor:
-    """[Cout,Cin,KH,KW] -> bf16 [Cout,KH,KW,Cin]."""
-    return w_oihw.permute(0, 2, 3, 1).contiguous().to(BF16)
+def pack_conv_weight(w_oihw: torch.Tensor, dtype=BF16) -> torch.Tensor:
+    """[Cout,Cin,KH,KW] -> [Cout,KH,KW,Cin] (bf16 unless another dtype is asked for)."""
+    return w_oihw.permute(0, 2, 3, 1).contiguous().to(dtype)
 
 
-def pack_conv_weight_narrow(w_oihw: torch.Tensor) -> torch.Tensor:
-    """[Cout,Cin,KH,KW] with Cin of 8, 16 or 32 -> bf16 [Cout,KH,ceil(KW/P),P*Cin], P = 64/Cin:
+def pack_conv_weight_narrow(w_oihw: torch.Tensor, dtype=BF16) -> torch.Tensor:
+    """[Cout,Cin,KH,KW] with Cin of 8, 16 or 32 -> [Cout,KH,ceil(KW/P),P*Cin], P = 64/Cin:
     run c of a filter row holds taps kw = c*P .. c*P+P-1 pixel by pixel, zero past the filter."""
     cout, cin, kh, kw = w_oihw.shape
     if cin not in (8, 16, 32):
@@ -35,7 +35,7 @@ def pack_conv_weight_narrow(w_oihw: torch.Tensor) -> torch.Tensor:
     kwc = (kw + P - 1) // P
     out = torch.zeros(cout, kh, kwc * P, cin, dtype=w_oihw.dtype, device=w_oihw.device)
     out[:, :, :kw, :] = w_oihw.permute(0, 2, 3, 1)
-    return out.reshape(cout, kh, kwc, P * cin).contiguous().to(BF16)
+    return out.reshape(cout, kh, kwc, P * cin).contiguous().to(dtype)
 
 
 def deconv_phase_taps(py: int, a: int):
@@ -263,7 +263,7 @@ IMAGENET_MEAN = (0.485, 0.456, 0.406)
 IMAGENET_STD = (0.229, 0.224, 0.225)
 
 
-def pack_stem3x3_weight(w_oihw: torch.Tensor) -> torch.Tensor:
+def pack_stem3x3_weight(w_oihw: torch.Tensor, dtype=BF16) -> torch.Tensor:
     """3x3 stride-2 pad-1 stem weight [Cout,3,3,3] -> bf16 [Cout, 2 rows, 4 cols * 16] for the
     equivalent 2-row conv over the 2x2 space-to-depth image (channel = (ry*2+rx)*3+c).  Kernel
     row ky reads s2d row offset (ky+1)//2 - 1 at parity (ky+1) % 2, and likewise for columns."""
@@ -275,7 +275,7 @@ def pack_stem3x3_weight(w_oihw: torch.Tensor) -> torch.Tensor:
             q, rx = (kx + 1) // 2, (kx + 1) % 2
             s = (ry * 2 + rx) * 3
             out[:, r, q, s:s + 3] = w_oihw[:, :, ky, kx]
-    return out.reshape(cout, 2, 64).contiguous().to(BF16)
+    return out.reshape(cout, 2, 64).contiguous().to(dtype)
 
 
 def stem3x3s2(x_s2d: torch.Tensor, w: torch.Tensor, scale=None, shift=None, relu: int = 2,
