@@ -497,10 +497,70 @@ class Train(Workload):
                           f"batch {B}, one run ({dt:.1f} s)"}
 
 
+class HRNetTrain(Workload):
+    """BASELINE configs[4]: full training step of the HRNet-W32-style multi-branch network at
+    384x288 -> 96x72 heat maps (forward with batch statistics, fused target render + masked MSE,
+    backward, gradient all-reduce when N > 1, fused Adam), batch 64 per GPU."""
+    name = "hrnet_w32_pose_train_384x288_b64_bf16"
+    batch = 64
+    heatmap = (96, 72)
+    dtype = "bf16"
+    bound = "mfma"
+    kernel = "igemm_kernel + wgrad_kernel (all launches of one step)"
+    peak = 2500.0
+    sharding = "data parallel: batch per rank, bucketed gradient all-reduce (RCCL) behind backward"
+
+    def setup(self, device):
+        import torch.distributed as dist
+
+        from pose_estimation_amd import hrnet
+
+        self.net = hrnet.TrainablePoseHRNet(device)
+        self.net.load_state(hrnet.init_state(self.net.spec, seed=3))
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            self.net.enable_data_parallel(32 << 20)
+        self.flops_per_step = 3 * 2.0 * hrnet.forward_macs(self.net.spec, 384, 288) * self.batch
+        rank = dist.get_rank() if dist.is_initialized() else 0
+        self.imgs = torch.from_numpy(synthetic.images_u8(self.batch, 384, 288, seed=1 + rank)).to(device)
+        self.joints = torch.from_numpy(synthetic.joints(self.batch, K_JOINTS, 384, 288,
+                                                        seed=2 + rank)).to(device)
+        self.mask = torch.from_numpy(synthetic.ignore_mask(self.batch, 96, 72, seed=4 + rank)).to(device)
+
+    def step(self, i):
+        self.net.train_step(self.imgs, self.joints, self.mask, lr=1e-3)
+
+    def roofline(self, kern_ms):
+        ach = self.flops_per_step / (kern_ms * 1e-3) / 1e12
+        return {"bound": "mfma", "kernel": self.kernel, "achieved": ach, "peak": self.peak,
+                "unit": "TFLOP/s", "frac": ach / self.peak,
+                "flops_per_step": self.flops_per_step, "step_ms": kern_ms, "traffic": None}
+
+    def cpu_baseline(self):
+        import oracle
+        from oracle import torch_oracle as to
+        from pose_estimation_amd import hrnet
+        from pose_estimation_amd import nn as pnn
+
+        spec = hrnet.hrnet_specs()
+        state = hrnet.init_state(spec, seed=3)
+        B = 2
+        img = synthetic.images_u8(B, 384, 288, seed=1)
+        j = synthetic.joints(B, K_JOINTS, 384, 288, seed=2)
+        m = synthetic.ignore_mask(B, 96, 72, seed=4)
+        t0 = time.perf_counter()
+        t, w = oracle.render_targets(j, 96, 72, 4.0, 3.0, 9)
+        to.hrnet_train_reference(spec, state, img, t, w, m, pnn.IMAGENET_MEAN, pnn.IMAGENET_STD)
+        dt = time.perf_counter() - t0
+        return {"value": B / dt, "unit": "images/s", "cores": torch.get_num_threads(),
+                "kind": "port",
+                "sample": f"torch-CPU autograd oracle (render + loss + backward, no optimizer), "
+                          f"batch {B}, one run ({dt:.1f} s)"}
+
+
 WORKLOADS = {"decode": Decode, "render": Render, "mse": Mse, "mse_fused": MseFused, "adam": Adam,
              "vecmap": VecRender, "vecmap_loss": VecLoss, "mobilenet": MobileNetInfer,
              "augment": Augment, "hrnet": HRNetInfer,
-             "infer": Infer, "train": Train}
+             "infer": Infer, "train": Train, "hrnet_train": HRNetTrain}
 
 
 def main() -> None:

@@ -35,13 +35,26 @@ class Trainer:
     # ------------------------------------------------------------------ model
     def build_model(self, state: Optional[Dict[str, torch.Tensor]] = None, seed: int = 3):
         m = self.model_cfg
-        if m.backbone != "resnet50":
+        if m.backbone == "resnet50":
+            self.net = TrainablePoseResNet(self.device, num_joints=m.num_joints,
+                                           layers=tuple(m.layers), head_ch=m.head_channels,
+                                           bn_momentum=m.bn_momentum, sigma=m.sigma,
+                                           heatmap_stride=float(m.heatmap_stride))
+            self.net.load_state(state if state is not None else init_state(self.net.specs, seed))
+        elif m.backbone in ("hrnet_w32", "hrnet"):
+            from . import hrnet
+
+            if int(m.heatmap_stride) != 4:
+                raise ValueError("the HRNet-style network predicts at stride 4")
+            self.net = hrnet.TrainablePoseHRNet(
+                self.device, num_joints=m.num_joints, width=int(m.get("width", 32)),
+                modules=tuple(m.get("modules", (1, 4, 3))), blocks=int(m.get("blocks", 4)),
+                layer1_blocks=int(m.get("layer1_blocks", 4)), bn_momentum=m.bn_momentum,
+                sigma=m.sigma, heatmap_stride=4.0)
+            self.net.load_state(state if state is not None
+                                else hrnet.init_state(self.net.spec, seed))
+        else:
             raise NotImplementedError(f"backbone {m.backbone!r} is not built yet")
-        self.net = TrainablePoseResNet(self.device, num_joints=m.num_joints,
-                                       layers=tuple(m.layers), head_ch=m.head_channels,
-                                       bn_momentum=m.bn_momentum, sigma=m.sigma,
-                                       heatmap_stride=float(m.heatmap_stride))
-        self.net.load_state(state if state is not None else init_state(self.net.specs, seed))
         import torch.distributed as dist
 
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:

@@ -171,3 +171,41 @@ def test_full_width_step_runs_at_384x288():
     assert torch.isfinite(net.master).all()
     hm = net.predict(img)
     assert tuple(hm.shape) == (2, 17, 96, 72)
+
+
+def test_layers_are_announced_to_the_bucketer_in_descending_arena_order():
+    """A branched backward finishes layers out of arena order; the gradient exchange is told
+    about a layer only once every layer above it is finished, and about every layer."""
+    class Recorder:
+        grad_scale = 0.5
+
+        def __init__(self):
+            self.calls = []
+
+        def layer_done(self, start):
+            self.calls.append(start)
+
+        def finish(self):
+            pass
+
+    net, state, img, joints, mask = make_case(2, 64, 64, seed=23)
+    net.bucketer = Recorder()
+    net.train_step(torch.from_numpy(img).cuda(), torch.from_numpy(joints).cuda(), lr=1e-3)
+    assert net.bucketer.calls == sorted(net.layer_starts, reverse=True)
+
+
+def test_trainer_builds_and_steps_the_hrnet_backbone():
+    from pose_estimation_amd import Trainer
+
+    tr = Trainer({"model_config": {"backbone": "hrnet_w32", "modules": [1, 1, 1], "blocks": 1,
+                                   "layer1_blocks": 1, "sigma": 2.0},
+                  "train_config": {"batch_size": 4, "preprocess": {"image_resize": [128, 96]}}},
+                 device="cuda:0")
+    tr.build_model()
+    losses = []
+    for feats, labels in tr.get_features_labels_data(num_batches=3):
+        losses.append(tr.train_step(feats, labels).item())
+    assert all(np.isfinite(losses))
+    hm = tr.predict(feats["images"])
+    xy, conf, idx = tr.decode(hm)
+    assert tuple(hm.shape) == (4, 17, 32, 24) and tuple(xy.shape) == (4, 17, 2)
