@@ -557,10 +557,70 @@ class HRNetTrain(Workload):
                           f"batch {B}, one run ({dt:.1f} s)"}
 
 
+class MobileNetTrain(Workload):
+    """The reference's own network family and label layout: MobileNetV2 (output stride 8) with
+    heat-map and vector-map heads (19 keypoint pairs), 320x320 images -> 40x40 maps, full
+    training step (forward with batch statistics, both label renders fused into their losses,
+    backward, gradient all-reduce when N > 1, fused Adam), batch 64 per GPU."""
+    name = "mobilenetv2_pose_train_320x320_b64_bf16"
+    batch = 64
+    heatmap = (40, 40)
+    dtype = "bf16"
+    bound = "hbm"
+    kernel = "all launches of one step (depthwise, batch-norm and thin pointwise layers)"
+    peak = 2500.0
+    sharding = "data parallel: batch per rank, bucketed gradient all-reduce (RCCL) behind backward"
+
+    def setup(self, device):
+        import torch.distributed as dist
+
+        from pose_estimation_amd import mobilenet as mb
+
+        self.net = mb.TrainablePoseMobileNetV2(device, pairs=mb.COCO_PAIRS)
+        self.net.load_state(mb.init_state(self.net.blocks, K_JOINTS, len(mb.COCO_PAIRS), seed=3))
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            self.net.enable_data_parallel(32 << 20)
+        self.flops_per_step = 3 * 2.0 * mb.forward_macs(320, 320, K_JOINTS, len(mb.COCO_PAIRS)) \
+            * self.batch
+        rank = dist.get_rank() if dist.is_initialized() else 0
+        self.imgs = torch.from_numpy(synthetic.images_u8(self.batch, 320, 320, seed=1 + rank)).to(device)
+        self.joints = torch.from_numpy(synthetic.joints(self.batch, K_JOINTS, 320, 320,
+                                                        seed=2 + rank)).to(device)
+
+    def step(self, i):
+        self.net.train_step(self.imgs, self.joints, None, lr=1e-3)
+
+    def roofline(self, kern_ms):
+        ach = self.flops_per_step / (kern_ms * 1e-3) / 1e12
+        return {"bound": "mfma", "kernel": self.kernel, "achieved": ach, "peak": self.peak,
+                "unit": "TFLOP/s", "frac": ach / self.peak,
+                "flops_per_step": self.flops_per_step, "step_ms": kern_ms, "traffic": None}
+
+    def cpu_baseline(self):
+        from oracle import torch_oracle as to
+        from pose_estimation_amd import mobilenet as mb
+        from pose_estimation_amd import nn as pnn
+
+        blocks = mb.mobilenet_v2_specs()
+        state = mb.init_state(blocks, K_JOINTS, len(mb.COCO_PAIRS), seed=3)
+        B = 4
+        img = synthetic.images_u8(B, 320, 320, seed=1)
+        dh = np.zeros((B, K_JOINTS, 40, 40), np.float32)
+        dv = np.zeros((B, 4 * len(mb.COCO_PAIRS), 40, 40), np.float32)
+        t0 = time.perf_counter()
+        to.mobilenet_train_reference(blocks, state, img, pnn.IMAGENET_MEAN, pnn.IMAGENET_STD, dh, dv)
+        dt = time.perf_counter() - t0
+        return {"value": B / dt, "unit": "images/s", "cores": torch.get_num_threads(),
+                "kind": "port",
+                "sample": f"torch-CPU autograd oracle (forward + backward from given head "
+                          f"gradients, no loss, no optimizer), batch {B}, one run ({dt:.1f} s)"}
+
+
 WORKLOADS = {"decode": Decode, "render": Render, "mse": Mse, "mse_fused": MseFused, "adam": Adam,
              "vecmap": VecRender, "vecmap_loss": VecLoss, "mobilenet": MobileNetInfer,
              "augment": Augment, "hrnet": HRNetInfer,
-             "infer": Infer, "train": Train, "hrnet_train": HRNetTrain}
+             "infer": Infer, "train": Train, "hrnet_train": HRNetTrain,
+             "mobilenet_train": MobileNetTrain}
 
 
 def main() -> None:

@@ -252,6 +252,20 @@ int32_t pe_depthwise3x3_fwd_bf16(const void* x, int32_t B, int32_t H, int32_t W,
                                  const float* scale, const float* shift, int32_t relu, void* y,
                                  pe_stream_t stream);
 
+/* Backward of the depthwise 3x3 conv (same geometry arguments: H, W are the INPUT size).
+ *   bwd_data  : dx [B,H,W,C] bf16 from dy [B,Ho,Wo,C] bf16 and the forward weight w [9][C].
+ *   bwd_weight: dw (float32 [9][C], caller zeroes it) += sum over cells of dy * shifted x, in
+ *               two ordered stages through `workspace`
+ *               (pe_depthwise3x3_bwd_weight_workspace_bytes(C)): bit-stable from run to run. */
+int32_t pe_depthwise3x3_bwd_data_bf16(const void* dy, int32_t B, int32_t H, int32_t W, int32_t C,
+                                      int32_t stride, int32_t dilation, const void* w, void* dx,
+                                      pe_stream_t stream);
+size_t pe_depthwise3x3_bwd_weight_workspace_bytes(int32_t C);
+int32_t pe_depthwise3x3_bwd_weight_bf16(const void* x, const void* dy, int32_t B, int32_t H,
+                                        int32_t W, int32_t C, int32_t stride, int32_t dilation,
+                                        float* dw, void* workspace, size_t workspace_bytes,
+                                        pe_stream_t stream);
+
 /* uint8 RGB [B,H,W,3] -> (x/255 - mean[c]) / std[c] -> bf16 space-to-depth [B,H/2,W/2,16]. */
 int32_t pe_preprocess_u8_s2d_bf16(const uint8_t* img, int32_t B, int32_t H, int32_t W,
                                   const float* mean3, const float* std3, void* x_s2d,

@@ -485,3 +485,88 @@ def hrnet_train_reference(spec, state, img_u8, targets, weights, mask, mean, std
     loss = 0.5 * e.mean()
     loss.backward()
     return loss.item(), hm.detach(), {k: p.grad for k, p in P.items()}
+
+
+# ----------------------------------------------------------------------------------------------
+# MobileNetV2 training: inverted-residual blocks with batch-statistics BN and ReLU6.
+# ----------------------------------------------------------------------------------------------
+class _Relu6Stored(torch.autograd.Function):
+    """ReLU6 whose output is stored in bf16 and whose backward masks with that stored value
+    (0 < a < 6), as a kernel that keeps only the bf16 activation must; the gradient is rounded
+    to bf16 as well."""
+
+    @staticmethod
+    def forward(ctx, y):
+        a = bf16r(torch.clamp(y, 0.0, 6.0))
+        ctx.save_for_backward(a)
+        return a
+
+    @staticmethod
+    def backward(ctx, g):
+        (a,) = ctx.saved_tensors
+        return bf16r(g) * ((a > 0) & (a < 6)).to(g.dtype)
+
+
+def _mb_block_autograd(b, P, x, round_bf16: bool, bn_eps: float):
+    rb = _RoundBoth.apply if round_bf16 else (lambda t: t)
+    rw = _RoundFwd.apply if round_bf16 else (lambda t: t)
+
+    def bn(name, z, relu6, residual=None):
+        y = F.batch_norm(z, None, None, P[name + ".bn.gamma"], P[name + ".bn.beta"],
+                         training=True, momentum=0.0, eps=bn_eps)
+        if residual is not None:
+            y = y + residual
+        if not relu6:
+            return rb(y)
+        return _Relu6Stored.apply(y) if round_bf16 else torch.clamp(y, 0.0, 6.0)
+
+    h = x
+    if b.expand != 1:
+        n = b.name + ".expand"
+        h = bn(n, rb(F.conv2d(h, rw(P[n + ".weight"]))), True)
+    n = b.name + ".dw"
+    h = bn(n, rb(F.conv2d(h, rw(P[n + ".weight"]), None, stride=b.stride, padding=b.dilation,
+                          dilation=b.dilation, groups=b.mid)), True)
+    n = b.name + ".project"
+    return bn(n, rb(F.conv2d(h, rw(P[n + ".weight"]))), False, residual=x if b.residual else None)
+
+
+def _grad_params(state):
+    return {k: v.clone().float().requires_grad_(True) for k, v in state.items()
+            if not (k.endswith(".bn.mean") or k.endswith(".bn.var"))}
+
+
+def mobilenet_block_train_reference(b, state, x_nhwc, dout_nhwc, bn_eps: float = 1e-5):
+    """Forward (batch statistics) + autograd backward of ONE inverted-residual block on the CPU
+    with bf16 rounding at the kernels' storage points.  Returns (out NHWC, dx NHWC, {name: grad})."""
+    P = {k: v for k, v in _grad_params(state).items() if k.startswith(b.name + ".")}
+    x = _nchw(x_nhwc).requires_grad_(True)
+    out = _mb_block_autograd(b, P, x, True, bn_eps)
+    out.backward(_nchw(dout_nhwc))
+    return _nhwc(out.detach()), _nhwc(x.grad), {k: p.grad for k, p in P.items() if p.grad is not None}
+
+
+def mobilenet_train_reference(blocks, state, img_u8, mean, std, dheat, dvec=None,
+                              bn_eps: float = 1e-5, round_bf16: bool = True):
+    """Forward with batch statistics and autograd backward of the whole MobileNetV2 pose network,
+    the heads seeded with given gradients (float32 [B,K,H,W] / [B,4P,H,W]) instead of a loss.
+    Returns (heat, vec or None, {name: grad in framework layout})."""
+    rb = _RoundBoth.apply if round_bf16 else (lambda t: t)
+    rw = _RoundFwd.apply if round_bf16 else (lambda t: t)
+    P = _grad_params(state)
+    x = torch.from_numpy(preprocess_u8(img_u8, mean, std)).permute(0, 3, 1, 2).contiguous()
+    z = rb(F.conv2d(x, rw(P["stem.weight"]), None, stride=2, padding=1))
+    y = F.batch_norm(z, None, None, P["stem.bn.gamma"], P["stem.bn.beta"], training=True,
+                     momentum=0.0, eps=bn_eps)
+    x = _Relu6Stored.apply(y) if round_bf16 else torch.clamp(y, 0.0, 6.0)
+    for b in blocks:
+        x = _mb_block_autograd(b, P, x, round_bf16, bn_eps)
+    heat = F.conv2d(x, rw(P["heat.weight"]), P["heat.bias"])
+    outs, seeds = [heat], [torch.as_tensor(dheat)]
+    vec = None
+    if dvec is not None:
+        vec = F.conv2d(x, rw(P["vec.weight"]), P["vec.bias"])
+        outs.append(vec)
+        seeds.append(torch.as_tensor(dvec))
+    torch.autograd.backward(outs, seeds)
+    return heat.detach(), None if vec is None else vec.detach(), {k: p.grad for k, p in P.items()}

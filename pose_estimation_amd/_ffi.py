@@ -158,6 +158,11 @@ SIGNATURES = {
         c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_int32, c_int32,
                   c_int32, c_void_p, c_void_p]),
     "pe_add_bf16": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
+    "pe_depthwise3x3_bwd_data_bf16": (
+        c_int32, [c_void_p] + [c_int32] * 6 + [c_void_p, c_void_p, c_void_p]),
+    "pe_depthwise3x3_bwd_weight_workspace_bytes": (c_size_t, [c_int32]),
+    "pe_depthwise3x3_bwd_weight_bf16": (
+        c_int32, [c_void_p, c_void_p] + [c_int32] * 6 + [c_void_p, c_void_p, c_size_t, c_void_p]),
     "pe_fuse_upsample_add_bf16": (
         c_int32, [c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_int32, c_int32, c_int32,
                   c_int32, c_void_p, c_void_p]),

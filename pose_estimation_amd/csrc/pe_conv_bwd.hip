@@ -610,12 +610,19 @@ extern "C" int32_t pe_final_grad_prepare_bf16(const float* g_nchw, int32_t B, in
                                               int32_t HW, int32_t Kpad, void* out_nhwc,
                                               float* dbias, pe_stream_t stream) {
     PE_REQUIRE(g_nchw && out_nhwc, PE_E_INVALID, "pe_final_grad_prepare_bf16: NULL pointer");
-    PE_REQUIRE(B > 0 && K > 0 && HW > 0 && K <= 32 && Kpad >= K && Kpad % 8 == 0 && Kpad <= 112,
+    PE_REQUIRE(B > 0 && K > 0 && HW > 0 && Kpad >= K && Kpad % 8 == 0 && Kpad <= 256,
                PE_E_UNSUPPORTED,
-               "pe_final_grad_prepare_bf16: need 0 < K <= 32, Kpad >= K, Kpad %% 8 == 0, Kpad <= 112");
+               "pe_final_grad_prepare_bf16: need K > 0, Kpad >= K, Kpad %% 8 == 0, Kpad <= 256");
     PE_REQUIRE(aligned(out_nhwc, 16), PE_E_INVALID, "pe_final_grad_prepare_bf16: output misaligned");
     const long npix = (long)B * HW;
     const size_t lds = (size_t)256 * (Kpad + 8) * sizeof(uint16_t);
+    if (lds > 64 * 1024) {   // 160 KB of LDS per CU; anything above 64 KB is opt-in
+        static const hipError_t once = hipFuncSetAttribute(
+            reinterpret_cast<const void*>(&final_grad_prepare_kernel),
+            hipFuncAttributeMaxDynamicSharedMemorySize, 256 * (256 + 8) * (int)sizeof(uint16_t));
+        PE_REQUIRE(once == hipSuccess, PE_E_HIP, "pe_final_grad_prepare_bf16: LDS opt-in: %s",
+                   hipGetErrorString(once));
+    }
     final_grad_prepare_kernel<<<(unsigned)((npix + 255) / 256), 256, lds, as_stream(stream)>>>(
         g_nchw, npix, K, HW, Kpad, static_cast<uint16_t*>(out_nhwc));
     const int32_t rc = check_launch("pe_final_grad_prepare_bf16");

@@ -203,9 +203,208 @@ __global__ __launch_bounds__(256) void depthwise3x3_s1_kernel(const uint16_t* __
     }
 }
 
+// Backward-data in gather form: an input cell sums, over the taps that reach it, weight x
+// output gradient.  dx[b,iy,ix,c] = sum_{ky,kx} w[ky*3+kx][c] * dy[b,oy,ox,c] with
+// oy*stride + (ky-1)*dil = iy (and likewise for x).  One thread per 8 channels of an input
+// cell, nine branch-free loads (taps that do not land on an output read a valid address and
+// are zeroed), float32 sum in tap order, one rounding.
+__global__ __launch_bounds__(256) void depthwise3x3_bwd_data_kernel(
+    const uint16_t* __restrict__ dy, int B, int H, int W, int C, int stride, int dil,
+    const uint16_t* __restrict__ w, uint16_t* __restrict__ dx, int Ho, int Wo) {
+    const int C8 = C >> 3;
+    const long total = (long)B * H * W * C8;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+        const int c8 = (int)(e % C8);
+        long r = e / C8;
+        const int ix = (int)(r % W);
+        r /= W;
+        const int iy = (int)(r % H);
+        const long b = r / H;
+        uint4 gv[9];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            const int ny = iy - (ky - 1) * dil;
+            const int oy = ny / stride;
+            const bool oky = ny >= 0 && ny == oy * stride && oy < Ho;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int nx = ix - (kx - 1) * dil;
+                const int ox = nx / stride;
+                const bool ok = oky && nx >= 0 && nx == ox * stride && ox < Wo;
+                const long off = ok ? (((b * Ho + oy) * Wo + ox) * (long)C8 + c8) * 8 : (long)c8 * 8;
+                uint4 v = *reinterpret_cast<const uint4*>(dy + off);
+                if (!ok) v = make_uint4(0u, 0u, 0u, 0u);
+                gv[ky * 3 + kx] = v;
+            }
+        }
+        float acc[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = 0.0f;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            float gf[8], wf[8];
+            dw_unpack(gv[t], gf);
+            dw_unpack(*reinterpret_cast<const uint4*>(w + ((long)t * C8 + c8) * 8), wf);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] += gf[i] * wf[i];
+        }
+        uint4 o;
+        o.x = pack_bf16x2_bits(acc[0], acc[1]);
+        o.y = pack_bf16x2_bits(acc[2], acc[3]);
+        o.z = pack_bf16x2_bits(acc[4], acc[5]);
+        o.w = pack_bf16x2_bits(acc[6], acc[7]);
+        *reinterpret_cast<uint4*>(dx + e * 8) = o;
+    }
+}
+
+// Backward-weight: dw[t][c] = sum over output cells of dy[cell][c] * x[cell*stride + tap t][c].
+// A reduction over every cell per channel, in two ordered stages (no float atomics): a workgroup
+// walks a contiguous range of output cells, thread (row lane, channel group) keeping 9 x 8
+// float32 sums, folds its row lanes through LDS in lane order and writes one partial
+// [9][C] block; the second kernel adds the blocks in order and accumulates into dw.
+constexpr int kDwMaxBlocks = 512;
+
+__global__ __launch_bounds__(256) void depthwise3x3_bwd_weight_kernel(
+    const uint16_t* __restrict__ x, const uint16_t* __restrict__ dy, int B, int H, int W, int C,
+    int stride, int dil, int Ho, int Wo, long cells_blk, int rl, float* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* red = reinterpret_cast<float*>(smem);  // [rl][9][C]
+    const int C8 = C >> 3;
+    const int tid = threadIdx.x;
+    const int cgi = tid % C8;
+    const int rli = tid / C8;
+    const long M = (long)B * Ho * Wo;
+    const long m0 = (long)blockIdx.x * cells_blk;
+    long m1 = m0 + cells_blk;
+    if (m1 > M) m1 = M;
+    float acc[9][8];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[t][i] = 0.0f;
+    if (rli < rl) {
+        for (long m = m0 + rli; m < m1; m += rl) {
+            const int ox = (int)(m % Wo);
+            const long r = m / Wo;
+            const int oy = (int)(r % Ho);
+            const long b = r / Ho;
+            float gf[8];
+            dw_unpack(*reinterpret_cast<const uint4*>(dy + (m * C8 + cgi) * 8), gf);
+            uint4 xv[9];
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const int iy = oy * stride + (ky - 1) * dil;
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int ix = ox * stride + (kx - 1) * dil;
+                    const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
+                    const long off = ok ? (((b * H + iy) * W + ix) * (long)C8 + cgi) * 8 : (long)cgi * 8;
+                    uint4 v = *reinterpret_cast<const uint4*>(x + off);
+                    if (!ok) v = make_uint4(0u, 0u, 0u, 0u);
+                    xv[ky * 3 + kx] = v;
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                float xf[8];
+                dw_unpack(xv[t], xf);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) acc[t][i] += gf[i] * xf[i];
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) red[((long)rli * 9 + t) * C + cgi * 8 + i] = acc[t][i];
+    }
+    __syncthreads();
+    for (int e = tid; e < 9 * C; e += 256) {
+        float s = 0.0f;
+        for (int r = 0; r < rl; ++r) s += red[(long)r * 9 * C + e];
+        partial[(long)blockIdx.x * 9 * C + e] = s;
+    }
+}
+
+__global__ __launch_bounds__(256) void depthwise3x3_bwd_weight_fold_kernel(
+    const float* __restrict__ partial, int nblk, int n, float* __restrict__ dw) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= n) return;
+    float s = 0.0f;
+    for (int b = 0; b < nblk; ++b) s += partial[(long)b * n + e];
+    dw[e] += s;
+}
+
 }  // namespace pe
 
 using namespace pe;
+
+static int32_t dw_check(const char* what, int32_t B, int32_t H, int32_t W, int32_t C,
+                        int32_t stride, int32_t dilation) {
+    PE_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && C % 8 == 0, PE_E_UNSUPPORTED,
+               "%s: sizes must be positive and C a multiple of 8", what);
+    PE_REQUIRE((stride == 1 || stride == 2) && dilation >= 1 && dilation <= 64, PE_E_UNSUPPORTED,
+               "%s: stride must be 1 or 2 and dilation in [1, 64]", what);
+    PE_REQUIRE((long)B * H * W * (C / 8) < (1L << 40), PE_E_UNSUPPORTED, "%s: tensor too large", what);
+    return PE_OK;
+}
+
+extern "C" int32_t pe_depthwise3x3_bwd_data_bf16(const void* dy, int32_t B, int32_t H, int32_t W,
+                                                 int32_t C, int32_t stride, int32_t dilation,
+                                                 const void* w, void* dx, pe_stream_t stream) {
+    const char* what = "pe_depthwise3x3_bwd_data_bf16";
+    PE_REQUIRE(dy && w && dx, PE_E_INVALID, "%s: NULL pointer", what);
+    const int32_t rc = dw_check(what, B, H, W, C, stride, dilation);
+    if (rc != PE_OK) return rc;
+    PE_REQUIRE(aligned(dy, 16) && aligned(w, 16) && aligned(dx, 16), PE_E_INVALID,
+               "%s: tensors must be 16-byte aligned", what);
+    const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+    const long total = (long)B * H * W * (C / 8);
+    long blocks = (total + 255) / 256;
+    if (blocks > 256 * 64) blocks = 256 * 64;
+    depthwise3x3_bwd_data_kernel<<<(unsigned)blocks, 256, 0, as_stream(stream)>>>(
+        static_cast<const uint16_t*>(dy), B, H, W, C, stride, dilation,
+        static_cast<const uint16_t*>(w), static_cast<uint16_t*>(dx), Ho, Wo);
+    return check_launch(what);
+}
+
+extern "C" size_t pe_depthwise3x3_bwd_weight_workspace_bytes(int32_t C) {
+    return C > 0 ? (size_t)kDwMaxBlocks * 9 * (size_t)C * sizeof(float) : 16;
+}
+
+extern "C" int32_t pe_depthwise3x3_bwd_weight_bf16(const void* x, const void* dy, int32_t B,
+                                                   int32_t H, int32_t W, int32_t C, int32_t stride,
+                                                   int32_t dilation, float* dw, void* workspace,
+                                                   size_t workspace_bytes, pe_stream_t stream) {
+    const char* what = "pe_depthwise3x3_bwd_weight_bf16";
+    PE_REQUIRE(x && dy && dw && workspace, PE_E_INVALID, "%s: NULL pointer", what);
+    const int32_t rc = dw_check(what, B, H, W, C, stride, dilation);
+    if (rc != PE_OK) return rc;
+    PE_REQUIRE(C <= 2048, PE_E_UNSUPPORTED, "%s: at most 2048 channels", what);
+    PE_REQUIRE(aligned(x, 16) && aligned(dy, 16) && aligned(workspace, 16), PE_E_INVALID,
+               "%s: tensors must be 16-byte aligned", what);
+    const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
+    const long M = (long)B * Ho * Wo;
+    const int C8 = C / 8;
+    // row lanes: as many as fit 256 threads and 64 KB of LDS for the fold
+    int rl = 256 / C8;
+    const int rl_lds = (int)((64 * 1024) / ((size_t)9 * C * sizeof(float)));
+    if (rl > rl_lds) rl = rl_lds;
+    PE_REQUIRE(rl >= 1, PE_E_UNSUPPORTED, "%s: too many channels for the fold", what);
+    long cells = (M + kDwMaxBlocks - 1) / kDwMaxBlocks;
+    if (cells < (long)rl * 8) cells = (long)rl * 8;
+    const int nblk = (int)((M + cells - 1) / cells);
+    PE_REQUIRE((size_t)nblk * 9 * C * sizeof(float) <= workspace_bytes, PE_E_INVALID,
+               "%s: workspace too small", what);
+    hipStream_t st = as_stream(stream);
+    depthwise3x3_bwd_weight_kernel<<<nblk, 256, (size_t)rl * 9 * C * sizeof(float), st>>>(
+        static_cast<const uint16_t*>(x), static_cast<const uint16_t*>(dy), B, H, W, C, stride,
+        dilation, Ho, Wo, cells, rl, static_cast<float*>(workspace));
+    int32_t rc2 = check_launch(what);
+    if (rc2 != PE_OK) return rc2;
+    depthwise3x3_bwd_weight_fold_kernel<<<(9 * C + 255) / 256, 256, 0, st>>>(
+        static_cast<const float*>(workspace), nblk, 9 * C, dw);
+    return check_launch(what);
+}
 
 extern "C" int32_t pe_depthwise3x3_fwd_bf16(const void* x, int32_t B, int32_t H, int32_t W,
                                             int32_t C, int32_t stride, int32_t dilation,

@@ -30,19 +30,20 @@ from .parallel import GradBucketer
 
 BF16 = torch.bfloat16
 BN_EPS = 1e-5
-HEAD_KPAD = 64   # a head's loss gradient is zero-padded to this many channels for the MFMA passes
 NARROW = (8, 16, 32)
 
 
 @dataclass
 class Layer:
     name: str
-    kind: str            # "conv" | "stem3" (3x3/2 on the space-to-depth image) | "head"
+    kind: str            # "conv" | "dw" (depthwise 3x3) | "stem3" (3x3/2 on the space-to-depth
+                         # image) | "head" (1x1 conv + bias to float32 NCHW maps)
     cin: int
     cout: int
     k: int = 1
     stride: int = 1
     relu: int = 1        # activation after BN (+ residual): 0 none, 1 ReLU, 2 ReLU6
+    dilation: int = 1    # depthwise layers only
 
     @property
     def pad(self) -> int:
@@ -50,11 +51,18 @@ class Layer:
 
     @property
     def narrow(self) -> bool:
-        return self.kind != "stem3" and self.cin in NARROW
+        return self.kind in ("conv", "head") and self.cin in NARROW
+
+    @property
+    def kpad(self) -> int:
+        """A head's loss gradient is zero-padded to this many channels for the MFMA passes."""
+        return (self.cout + 63) // 64 * 64
 
     def packed_shape(self) -> Tuple[int, ...]:
         if self.kind == "stem3":
             return (self.cout, 2, 64)
+        if self.kind == "dw":
+            return (9, self.cout)
         if self.narrow:
             P = 64 // self.cin
             return (self.cout, self.k, (self.k + P - 1) // P, 64)
@@ -65,6 +73,8 @@ class Layer:
         w = w_oihw.float()
         if self.kind == "stem3":
             return pnn.pack_stem3x3_weight(w, torch.float32)
+        if self.kind == "dw":                       # [C,1,3,3] -> [9,C]
+            return w.reshape(self.cout, 9).t().contiguous()
         if self.narrow:
             return pnn.pack_conv_weight_narrow(w, torch.float32)
         return pnn.pack_conv_weight(w, torch.float32)
@@ -141,7 +151,7 @@ class TrainGraph:
                 shp = pnn.bwd_data_weight_shape(L.cin, L.cout, L.k, L.stride, L.pad)
                 self.wt[L.name] = torch.zeros(shp, dtype=BF16, device=dev)
             elif L.kind == "head":
-                self.wt[L.name] = torch.zeros(L.cin, 1, HEAD_KPAD, dtype=BF16, device=dev)
+                self.wt[L.name] = torch.zeros(L.cin, 1, L.kpad, dtype=BF16, device=dev)
             m = L.param_mask()
             if m is not None:
                 self.masks[L.name] = m.to(dev)
@@ -250,11 +260,28 @@ class TrainGraph:
         if not self.training:
             if L.kind == "stem3":
                 y = pnn.stem3x3s2(x.t, self.w(L), self.scale[L.name], self.shift[L.name], relu=act)
+            elif L.kind == "dw":
+                y = pnn.depthwise3x3(x.t, self.w(L), self.scale[L.name], self.shift[L.name],
+                                     L.stride, L.dilation, act)
+                if residual is not None:
+                    raise ValueError("a depthwise layer takes no residual")
             else:
                 y = pnn.conv2d(x.t, self.w(L), self.scale[L.name], self.shift[L.name], res_t,
                                L.stride, L.pad, act, **kw)
             return Var(y, False)
         B, H, W, _ = x.t.shape
+        gamma = self.view(self.master, L.name + ".bn.gamma")
+        beta = self.view(self.master, L.name + ".bn.beta")
+        if L.kind == "dw":
+            # bandwidth-bound conv without an epilogue, then one reduction pass for the statistics
+            z = pnn.depthwise3x3(x.t, self.w(L), None, None, L.stride, L.dilation, relu=0)
+            M = z.numel() // L.cout
+            _, _, scale, shift = pnn.bn_stats(z, gamma, beta, BN_EPS, self.bn_momentum,
+                                              self.bn_mean[L.name], self.bn_var[L.name],
+                                              self._workspace_for(M, L.cout), out=self.bn_buf[L.name])
+            out = Var(pnn.bn_apply(z, scale, shift, res_t, act))
+            self.tape.append(("unit", L, x, residual, act, z, out))
+            return out
         if L.kind == "stem3":
             M = B * H * W
             z, rows = pnn.stem3x3s2_bnstats(x.t, self.w(L), self._workspace_for(M, L.cout))
@@ -265,8 +292,7 @@ class TrainGraph:
             z, rows = pnn.conv2d_bnstats(x.t, self.w(L), self._workspace_for(M, L.cout), L.stride,
                                          L.pad, **kw)
         _, _, scale, shift = pnn.bn_finalize(
-            self._ws, rows, M, L.cout, self.view(self.master, L.name + ".bn.gamma"),
-            self.view(self.master, L.name + ".bn.beta"), BN_EPS, self.bn_momentum,
+            self._ws, rows, M, L.cout, gamma, beta, BN_EPS, self.bn_momentum,
             self.bn_mean[L.name], self.bn_var[L.name], out=self.bn_rows[L.name])
         out = Var(pnn.bn_apply(z, scale, shift, res_t, act))
         self.tape.append(("unit", L, x, residual, act, z, out))
@@ -326,6 +352,8 @@ class TrainGraph:
         with self._beside(x, dz):
             if L.kind == "stem3":
                 pnn.stem3x3s2_bwd_weight(x, dz, gw)
+            elif L.kind == "dw":
+                pnn.depthwise3x3_bwd_weight(x, dz, gw, L.stride, L.dilation)
             else:
                 pnn.conv2d_bwd_weight(x, dz, gw, L.k, L.stride, L.pad, cout=cout)
             m = self.masks.get(L.name)
@@ -337,6 +365,10 @@ class TrainGraph:
         if not x.needs_grad:
             return
         hw = tuple(x.t.shape[1:3])
+        if L.kind == "dw":
+            dx = pnn.depthwise3x3_bwd_data(dz, self.w(L), hw, L.stride, L.dilation)
+            x.grad = dx if x.grad is None else pnn.add_bf16(x.grad, dx)
+            return
         fused = x.grad is not None and not (L.k == 1 and L.stride == 2)
         dx = pnn.conv2d_bwd_data(dz, self.wt[L.name], hw, L.k, L.stride, L.pad,
                                  residual=x.grad if fused else None)
@@ -353,7 +385,7 @@ class TrainGraph:
             rec = self.tape.pop()
             if rec[0] == "head":
                 _, L, x = rec
-                dyp = pnn.final_grad_prepare(head_grads[L.name], HEAD_KPAD, self._g(L.name + ".bias"))
+                dyp = pnn.final_grad_prepare(head_grads[L.name], L.kpad, self._g(L.name + ".bias"))
                 self._weight_grad(L, x.t, dyp, cout=L.cout)
                 if x.needs_grad:
                     hw = tuple(x.t.shape[1:3])

@@ -24,6 +24,7 @@ import torch
 
 from . import nn as pnn
 from . import ops
+from .graph import Layer, TrainGraph, Var
 
 BF16 = torch.bfloat16
 BN_EPS = 1e-5
@@ -194,3 +195,123 @@ class PoseMobileNetV2:
 
     def decode(self, heatmaps: torch.Tensor):
         return ops.decode(heatmaps)
+
+
+# --------------------------------------------------------------------------------------------
+# Training (and inference from the same arenas) on the tape-based graph
+# --------------------------------------------------------------------------------------------
+# keypoint pairs of the 17-joint COCO skeleton (limbs), used when a model asks for vector maps
+# without naming its pairs
+COCO_PAIRS = [(15, 13), (13, 11), (16, 14), (14, 12), (11, 12), (5, 11), (6, 12), (5, 6), (5, 7),
+              (6, 8), (7, 9), (8, 10), (1, 2), (0, 1), (0, 2), (1, 3), (2, 4), (3, 5), (4, 6)]
+
+
+def _graph_layers(blocks: List[MBBlock], num_joints: int, num_pairs: int, stem_ch: int = 32):
+    layers = [Layer("stem", "stem3", 3, pad64(stem_ch), 3, 2, 2)]
+    for b in blocks:
+        if b.expand != 1:
+            layers.append(Layer(b.name + ".expand", "conv", pad64(b.cin), pad64(b.mid), 1, 1, 2))
+        layers.append(Layer(b.name + ".dw", "dw", pad64(b.mid), pad64(b.mid), 3, b.stride, 2,
+                            b.dilation))
+        layers.append(Layer(b.name + ".project", "conv", pad64(b.mid), pad64(b.cout), 1, 1, 0))
+    cf = pad64(blocks[-1].cout)
+    layers.append(Layer("heat", "head", cf, num_joints))
+    if num_pairs:
+        layers.append(Layer("vec", "head", cf, 4 * num_pairs))
+    return layers
+
+
+def pad_state(layers, st: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    """True-size framework-layout state -> the channel-padded sizes of the graph's layers.
+    Padded weights are zero and padded batch norms have gamma = beta = 0, so padded channels
+    hold exact zeros in every activation and receive exact zeros as gradients."""
+    out: Dict[str, torch.Tensor] = {}
+    for L in layers:
+        w = st[L.name + ".weight"]
+        if L.kind == "stem3":
+            shape = (L.cout, 3, 3, 3)
+        elif L.kind == "dw":
+            shape = (L.cout, 1, 3, 3)
+        else:
+            shape = (L.cout, L.cin, 1, 1)
+        wp = torch.zeros(shape)
+        wp[tuple(slice(0, n) for n in w.shape)] = w
+        out[L.name + ".weight"] = wp
+        if L.kind == "head":
+            out[L.name + ".bias"] = st[L.name + ".bias"]
+            continue
+        for nm, fill in ((".bn.gamma", 0.0), (".bn.beta", 0.0), (".bn.mean", 0.0), (".bn.var", 1.0)):
+            v = torch.full((L.cout,), fill)
+            v[:st[L.name + nm].numel()] = st[L.name + nm]
+            out[L.name + nm] = v
+    return out
+
+
+class TrainablePoseMobileNetV2(TrainGraph):
+    """MobileNetV2 backbone + heat-map (and vector-map) heads with the parameter arenas on one
+    GPU: forward with batch statistics, label rendering fused into the two losses, backward
+    (pointwise convs on the MFMA engine, depthwise convs on bandwidth kernels), fused optimizer;
+    `predict` runs the same graph with folded BN.  Labels follow the reference's notebook:
+    stride-8 maps, 3x3 supports (test.ipynb:606-653, 919)."""
+
+    def __init__(self, device, num_joints: int = 17, pairs=None, output_stride: int = 8,
+                 setting=None, bn_momentum: float = 0.1, sigma: float = 1.0, radius: int = 1):
+        self.blocks = mobilenet_v2_specs(output_stride, setting)
+        self.pairs = list(pairs) if pairs else []
+        self.num_joints = num_joints
+        self.num_pairs = len(self.pairs)
+        super().__init__(device, _graph_layers(self.blocks, num_joints, self.num_pairs), bn_momentum)
+        self.output_stride = output_stride
+        self.sigma = sigma
+        self.radius = radius
+
+    def load_state(self, st: Dict[str, torch.Tensor]) -> None:
+        super().load_state(pad_state(self.layers, st))
+
+    def block(self, b: MBBlock, x: Var) -> Var:
+        """One inverted-residual block: 1x1 expand, depthwise 3x3, linear 1x1 projection."""
+        L = self.by_name
+        h = x
+        if b.expand != 1:
+            h = self.unit(L[b.name + ".expand"], h)
+        h = self.unit(L[b.name + ".dw"], h)
+        return self.unit(L[b.name + ".project"], h, residual=x if b.residual else None)
+
+    def forward(self, x_s2d: torch.Tensor, training: bool):
+        self.begin(training)
+        L = self.by_name
+        x = self.unit(L["stem"], Var(x_s2d, False))
+        for b in self.blocks:
+            x = self.block(b, x)
+        heat = self.head(L["heat"], x)
+        return (heat, self.head(L["vec"], x)) if self.num_pairs else heat
+
+    def forward_train(self, images_u8: Optional[torch.Tensor],
+                      x_s2d: Optional[torch.Tensor] = None):
+        return self.forward(x_s2d if x_s2d is not None else pnn.preprocess_u8(images_u8), True)
+
+    def predict(self, images_u8: torch.Tensor):
+        """uint8 [B,H,W,3] -> heat maps (and vector maps), running BN statistics (call fold_bn()
+        after training steps)."""
+        return self.forward(pnn.preprocess_u8(images_u8), False)
+
+    def train_step(self, images_u8, joints: torch.Tensor, mask: Optional[torch.Tensor] = None,
+                   lr: float = 1e-3, optimizer: str = "adam", beta1: float = 0.9,
+                   beta2: float = 0.999, eps: float = 1e-8, momentum: float = 0.9,
+                   x_s2d: Optional[torch.Tensor] = None):
+        """One optimisation step on heat-map loss + vector-map loss; returns
+        (loss [1] device tensor, per_joint [K])."""
+        out = self.forward_train(images_u8, x_s2d)
+        heat = out[0] if self.num_pairs else out
+        s = float(self.output_stride)
+        loss, per_joint, grad, _ = ops.mse_fwd_bwd(heat, joints=joints, mask=mask, stride=s,
+                                                  sigma=self.sigma, radius=self.radius)
+        grads = {"heat": grad}
+        if self.num_pairs:
+            vloss, _, vgrad = ops.vecmap_loss_fwd_bwd(out[1], joints, self.pairs, s, self.radius,
+                                                      mask)
+            grads["vec"] = vgrad
+            loss = loss + vloss
+        self.backward(grads)
+        self.optimizer_step(lr, optimizer, beta1, beta2, eps, momentum)
+        return loss, per_joint

@@ -331,6 +331,48 @@ def depthwise3x3(x: torch.Tensor, w9c: torch.Tensor, scale=None, shift=None, str
     return out
 
 
+def depthwise3x3_bwd_data(dy: torch.Tensor, w9c: torch.Tensor, in_hw, stride: int = 1,
+                          dilation: int = 1, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """dx [B,H,W,C] of depthwise3x3 from dy [B,Ho,Wo,C] and the forward weight [9,C]."""
+    _check_act(dy, "dy")
+    B, Ho, Wo, C = dy.shape
+    H, W = in_hw
+    if (Ho, Wo) != ((H - 1) // stride + 1, (W - 1) // stride + 1):
+        raise ValueError("dy does not match the input size")
+    if w9c.dtype != BF16 or tuple(w9c.shape) != (9, C) or not w9c.is_contiguous():
+        raise ValueError("depthwise weight must be contiguous bfloat16 [9, C]")
+    if out is None:
+        out = torch.empty((B, H, W, C), dtype=BF16, device=dy.device)
+    with on_device(dy):
+        check(lib().pe_depthwise3x3_bwd_data_bf16(dy.data_ptr(), B, H, W, C, int(stride),
+                                                  int(dilation), w9c.data_ptr(), out.data_ptr(),
+                                                  _stream(dy)))
+    return out
+
+
+_dw_ws: dict = {}
+
+
+def depthwise3x3_bwd_weight(x: torch.Tensor, dy: torch.Tensor, dw: torch.Tensor, stride: int = 1,
+                            dilation: int = 1) -> None:
+    """dw (float32 [9,C], pre-zeroed) += weight gradient of depthwise3x3."""
+    _check_act(x)
+    _check_act(dy, "dy")
+    B, H, W, C = x.shape
+    if dw.dtype != torch.float32 or tuple(dw.shape) != (9, C) or not dw.is_contiguous():
+        raise ValueError("dw must be contiguous float32 [9, C]")
+    need = lib().pe_depthwise3x3_bwd_weight_workspace_bytes(C)
+    key = str(x.device)
+    ws = _dw_ws.get(key)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(need, dtype=torch.uint8, device=x.device)
+        _dw_ws[key] = ws
+    with on_device(x):
+        check(lib().pe_depthwise3x3_bwd_weight_bf16(x.data_ptr(), dy.data_ptr(), B, H, W, C,
+                                                    int(stride), int(dilation), dw.data_ptr(),
+                                                    ws.data_ptr(), ws.numel(), _stream(x)))
+
+
 def preprocess_u8(img: torch.Tensor, mean=IMAGENET_MEAN, std=IMAGENET_STD,
                   out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """uint8 [B,H,W,3] -> normalised bf16 space-to-depth [B,H/2,W/2,16]."""

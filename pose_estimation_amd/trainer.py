@@ -53,6 +53,17 @@ class Trainer:
                 sigma=m.sigma, heatmap_stride=4.0)
             self.net.load_state(state if state is not None
                                 else hrnet.init_state(self.net.spec, seed))
+        elif m.backbone in ("mobilenet_v2", "mobilenet"):
+            from . import mobilenet as mb
+
+            stride = int(m.heatmap_stride)
+            pairs = m.get("pairs")
+            self.net = mb.TrainablePoseMobileNetV2(
+                self.device, num_joints=m.num_joints,
+                pairs=[tuple(p) for p in pairs] if pairs else None, output_stride=stride,
+                bn_momentum=m.bn_momentum, sigma=m.sigma, radius=int(m.get("radius", 1)))
+            self.net.load_state(state if state is not None else mb.init_state(
+                self.net.blocks, m.num_joints, self.net.num_pairs, seed))
         else:
             raise NotImplementedError(f"backbone {m.backbone!r} is not built yet")
         import torch.distributed as dist

@@ -462,3 +462,33 @@ def test_fuse_upsample_add_backward(relu):
         close(got.float().cpu(), nhwc(t.grad), 4e-3)
     a, b = rnd((3, 5, 7, 8), g), rnd((3, 5, 7, 8), g)
     assert torch.equal(pnn.add_bf16(a.to(BF16).cuda(), b.to(BF16).cuda()).float().cpu(), to.bf16r(a + b))
+
+
+@pytest.mark.parametrize("case", [
+    # B, H, W, C, stride, dilation
+    (2, 12, 10, 64, 1, 1),
+    (2, 13, 11, 192, 2, 1),
+    (3, 10, 10, 96, 1, 2),
+    (2, 8, 8, 960, 1, 4),
+    (1, 16, 12, 24, 2, 1),
+])
+def test_depthwise_backward(case):
+    B, H, W, C, s, d = case
+    g = torch.Generator().manual_seed(97 + sum(case))
+    Ho, Wo = (H - 1) // s + 1, (W - 1) // s + 1
+    x = ints((B, H, W, C), g, -2, 2)
+    w = ints((C, 1, 3, 3), g, -1, 1)
+    dy = ints((B, Ho, Wo, C), g, -1, 1)
+    xt = nchw(x).requires_grad_(True)
+    wt_ = w.clone().requires_grad_(True)
+    y = F.conv2d(xt, wt_, None, stride=s, padding=d, dilation=d, groups=C)
+    assert tuple(y.shape[2:]) == (Ho, Wo)
+    y.backward(nchw(dy))
+    w9c = w.reshape(C, 9).t().contiguous().to(BF16).cuda()
+    dx = pnn.depthwise3x3_bwd_data(dy.to(BF16).cuda(), w9c, (H, W), s, d)
+    assert torch.equal(dx.float().cpu(), to.bf16r(nhwc(xt.grad)))
+    dw = torch.zeros(9, C, device="cuda")
+    pnn.depthwise3x3_bwd_weight(x.to(BF16).cuda(), dy.to(BF16).cuda(), dw, s, d)
+    assert torch.equal(dw.cpu(), wt_.grad.reshape(C, 9).t())
+    pnn.depthwise3x3_bwd_weight(x.to(BF16).cuda(), dy.to(BF16).cuda(), dw, s, d)   # accumulates
+    assert torch.equal(dw.cpu(), 2 * wt_.grad.reshape(C, 9).t())

@@ -1,0 +1,176 @@
+"""Training of the MobileNetV2 pose network (the reference's own backbone family,
+nets/mobilenet_v2.py / model/mobilenet_pose.py, PoseEstimation.pyproj:31-32, both absent) on the
+tape graph, against torch-CPU autograd of the same graph with bf16 rounding at the kernels'
+storage points.  Parity unpinned beyond the label layout the notebook shows.
+
+Single inverted-residual blocks, fed identical inputs and output gradients: outputs within one
+bf16 ulp of the largest value, gradients 2e-2 relative L2 per tensor.  Whole network: relative L2
+per tensor against max(3e-2, 3 x the float32-vs-bf16 spread of the CPU graph itself), as for the
+other networks.  The depthwise and pointwise kernels are pinned bit for bit in test_gpu_bwd.py.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import torch_oracle as to
+from pose_estimation_amd import mobilenet as mb
+from pose_estimation_amd import nn as pnn
+from pose_estimation_amd import ops
+from pose_estimation_amd import synthetic
+from pose_estimation_amd.graph import Var
+from pose_estimation_amd.model import randomize_bn
+
+pytestmark = pytest.mark.gpu
+SMALL = [(1, 16, 1, 1), (6, 24, 2, 2), (6, 32, 2, 2), (6, 64, 2, 2), (6, 96, 1, 1)]
+PAIRS = mb.COCO_PAIRS[:5]
+
+
+def rel_l2(a, b):
+    return ((a - b).norm() / (b.norm() + 1e-30)).item()
+
+
+def make_net(seed, setting=SMALL, pairs=PAIRS):
+    net = mb.TrainablePoseMobileNetV2("cuda:0", num_joints=17, pairs=pairs, setting=setting)
+    state = mb.init_state(net.blocks, 17, len(pairs), seed=seed)
+    randomize_bn(state, seed=seed + 1)
+    for k in ("heat.weight", "vec.weight"):
+        if k in state:
+            state[k] = state[k] * 30.0
+    net.load_state(state)
+    return net, state
+
+
+def true_slice(net, name, got, ref_shape):
+    """The true-size part of a channel-padded gradient, in the framework layout of `ref`."""
+    L = net.by_name[name.rsplit(".", 1)[0] if not name.endswith((".bn.gamma", ".bn.beta"))
+                    else name.rsplit(".", 2)[0]]
+    if not name.endswith(".weight"):
+        return got[:ref_shape[0]]
+    if L.kind == "dw":                                  # [9, Cpad] -> [C,1,3,3]
+        return got[:, :ref_shape[0]].t().reshape(ref_shape)
+    if L.kind == "stem3":
+        return None
+    return got[:ref_shape[0], 0, 0, :ref_shape[1]].reshape(ref_shape)
+
+
+def check_grads(net, rg, bound, fg=None):
+    for nm, ref in rg.items():
+        got = net.view(net.grads, nm).cpu()
+        if nm == "stem.weight":
+            L = net.by_name["stem"]
+            pad = torch.zeros(L.cout, 3, 3, 3)
+            pad[:ref.shape[0]] = ref
+            g2, r2 = got * net.masks["stem"].cpu(), L.pack(pad)
+            f2 = None
+            if fg is not None:
+                padf = torch.zeros(L.cout, 3, 3, 3)
+                padf[:ref.shape[0]] = fg[nm]
+                f2 = L.pack(padf)
+        else:
+            g2, r2 = true_slice(net, nm, got, tuple(ref.shape)), ref
+            f2 = fg[nm] if fg is not None else None
+            # nothing leaks into the padding
+            assert got.abs().sum().item() == pytest.approx(g2.abs().sum().item(), rel=1e-6), nm
+        e = rel_l2(g2, r2)
+        s = rel_l2(f2, r2) if f2 is not None else 0.0
+        print(f"   {nm:28s} rel L2 {e:.2e}   spread {s:.2e}")
+        assert e <= max(bound, 3 * s), nm
+
+
+def test_single_blocks_against_autograd():
+    net, state = make_net(seed=21)
+    g = torch.Generator().manual_seed(5)
+    B, H, W = 3, 16, 12
+    for b in net.blocks:
+        cin_p = mb.pad64(b.cin)
+        x = torch.zeros(B, H, W, cin_p)
+        x[..., :b.cin] = to.bf16r(torch.randn((B, H, W, b.cin), generator=g))
+        net.grads.zero_()
+        net.begin(True)
+        xv = Var(x.to(torch.bfloat16).cuda(), True)
+        out = net.block(b, xv)
+        Ho, Wo = out.t.shape[1:3]
+        dout = torch.zeros(B, Ho, Wo, mb.pad64(b.cout))
+        dout[..., :b.cout] = to.bf16r(torch.randn((B, Ho, Wo, b.cout), generator=g))
+        out.grad = dout.to(torch.bfloat16).cuda()
+        net.backward({})
+        torch.cuda.synchronize()
+        rout, rdx, rg = to.mobilenet_block_train_reference(b, state, x[..., :b.cin],
+                                                           dout[..., :b.cout])
+        o = out.t.float().cpu()
+        assert not o[..., b.cout:].any()                       # padded channels stay zero
+        err = (o[..., :b.cout] - rout).abs().max().item()
+        assert err <= 8e-3 * rout.abs().max().item() + 1e-6, b.name
+        dx = xv.grad.float().cpu()
+        assert not dx[..., b.cin:].any()
+        e = rel_l2(dx[..., :b.cin], rdx)
+        print(f"{b.name}: out err {err:.2e}, dx rel L2 {e:.2e}")
+        assert e <= 2e-2, b.name
+        check_grads(net, rg, 2e-2)
+
+
+def test_whole_network_against_autograd():
+    B, H, W = 4, 128, 96
+    net, state = make_net(seed=3)
+    img = synthetic.images_u8(B, H, W, seed=1)
+    joints = torch.from_numpy(synthetic.joints(B, 17, H, W, seed=2)).cuda()
+    heat, vec = net.forward_train(torch.from_numpy(img).cuda())
+    _, _, gh, _ = ops.mse_fwd_bwd(heat, joints=joints, stride=8.0, sigma=1.0, radius=1)
+    _, _, gv = ops.vecmap_loss_fwd_bwd(vec, joints, PAIRS, 8.0, 1)
+    gh, gv = gh * 1e3, gv * 1e3      # O(1e-3 .. 1) seeds: keeps bf16 gradients out of denormals
+    net.backward({"heat": gh, "vec": gv})
+    torch.cuda.synchronize()
+    args = (net.blocks, state, img, pnn.IMAGENET_MEAN, pnn.IMAGENET_STD, gh.cpu(), gv.cpu())
+    rheat, rvec, rg = to.mobilenet_train_reference(*args)
+    fheat, fvec, fg = to.mobilenet_train_reference(*args, round_bf16=False)
+    e_h, s_h = rel_l2(heat.cpu(), rheat), rel_l2(fheat, rheat)
+    e_v, s_v = rel_l2(vec.cpu(), rvec), rel_l2(fvec, rvec)
+    print(f"heat {e_h:.3e} (spread {s_h:.3e})  vec {e_v:.3e} (spread {s_v:.3e})")
+    assert e_h <= max(2e-2, 3 * s_h) and e_v <= max(2e-2, 3 * s_v)
+    check_grads(net, rg, 3e-2, fg)
+
+
+def test_training_reduces_the_loss_and_is_reproducible():
+    B, H, W = 8, 96, 96
+    losses = []
+    for rep in range(2):
+        net, state = make_net(seed=7)
+        it = torch.from_numpy(synthetic.images_u8(B, H, W, seed=1)).cuda()
+        jt = torch.from_numpy(synthetic.joints(B, 17, H, W, seed=2)).cuda()
+        run = []
+        for _ in range(12):
+            loss, _ = net.train_step(it, jt, lr=1e-3)
+            run.append(loss.item())
+        losses.append(run)
+    print("losses", losses[0])
+    assert losses[0][-1] < 0.8 * losses[0][0]
+    assert losses[0] == losses[1]
+    # channel padding stays exactly zero through the optimizer
+    for L in net.layers:
+        if L.kind == "conv":
+            b = next(bb for bb in net.blocks if L.name.startswith(bb.name + "."))
+            cin, cout = (b.cin, b.mid) if L.name.endswith(".expand") else (b.mid, b.cout)
+            w = net.view(net.master, L.name + ".weight")
+            assert not w[cout:].any() and not w[:, :, :, cin:].any(), L.name
+
+
+def test_inference_mode_matches_the_inference_network():
+    net, state = make_net(seed=17)
+    ref = mb.PoseMobileNetV2("cuda:0", num_joints=17, num_pairs=len(PAIRS), setting=SMALL)
+    ref.load_state(state)
+    it = torch.from_numpy(synthetic.images_u8(2, 128, 96, seed=1)).cuda()
+    (a, av), (b, bv) = net.predict(it), ref.predict(it)
+    assert rel_l2(a.cpu(), b.cpu()) <= 1e-2 and rel_l2(av.cpu(), bv.cpu()) <= 1e-2
+
+
+def test_full_network_step_runs_at_320x320():
+    net = mb.TrainablePoseMobileNetV2("cuda:0", num_joints=17, pairs=mb.COCO_PAIRS)
+    net.load_state(mb.init_state(net.blocks, 17, len(mb.COCO_PAIRS), seed=5))
+    img = torch.from_numpy(synthetic.images_u8(4, 320, 320, seed=1)).cuda()
+    joints = torch.from_numpy(synthetic.joints(4, 17, 320, 320, seed=2)).cuda()
+    l0, _ = net.train_step(img, joints, lr=1e-3)
+    l1, _ = net.train_step(img, joints, lr=1e-3)
+    assert np.isfinite(l0.item()) and np.isfinite(l1.item())
+    assert torch.isfinite(net.master).all()
+    heat, vec = net.predict(img)
+    assert tuple(heat.shape) == (4, 17, 40, 40) and tuple(vec.shape) == (4, 76, 40, 40)
