@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256) void depthwise3x3_s1_kernel(const uint16_t* __
                                                               const float* __restrict__ scale,
                                                               const float* __restrict__ shift,
                                                               int relu, uint16_t* __restrict__ y,
-                                                              int nty, int ntx) {
+                                                              int nty, int ntx, int flip) {
     const int C4 = C >> 2;
     const long total = (long)B * nty * ntx * C4;
     const long e = (long)blockIdx.x * 256 + threadIdx.x;
@@ -133,7 +133,8 @@ __global__ __launch_bounds__(256) void depthwise3x3_s1_kernel(const uint16_t* __
     float wf[9][4];
 #pragma unroll
     for (int t = 0; t < 9; ++t)
-        dw_unpack4(*reinterpret_cast<const uint2*>(w + ((long)t * C4 + c4) * 4), wf[t]);
+        dw_unpack4(*reinterpret_cast<const uint2*>(w + ((long)(flip ? 8 - t : t) * C4 + c4) * 4),
+                   wf[t]);  // flip: the spatially mirrored filter = the stride-1 backward-data pass
     float acc[DW_TY][DW_TX][4];
 #pragma unroll
     for (int a = 0; a < DW_TY; ++a)
@@ -325,12 +326,33 @@ __global__ __launch_bounds__(256) void depthwise3x3_bwd_weight_kernel(
     }
 }
 
+// Second stage: a workgroup folds the partial blocks of 4 elements; thread (slice, element) adds
+// blocks slice, slice + 64, ... eight loads at a time, then slice 0 adds the 64 slice sums in
+// order.  The order of additions depends on (nblk, n) alone.
 __global__ __launch_bounds__(256) void depthwise3x3_bwd_weight_fold_kernel(
     const float* __restrict__ partial, int nblk, int n, float* __restrict__ dw) {
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= n) return;
+    __shared__ float red[64][5];
+    const int el = threadIdx.x & 3;
+    const int slice = threadIdx.x >> 2;
+    const int e = blockIdx.x * 4 + el;
+    float a = 0.0f;
+    if (e < n) {
+        for (int b0 = slice; b0 < nblk; b0 += 64 * 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int b = b0 + u * 64;
+                const float x = partial[(long)(b < nblk ? b : b0) * n + e];
+                v[u] = b < nblk ? x : 0.0f;
+            }
+            a += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+        }
+    }
+    red[slice][el] = a;
+    __syncthreads();
+    if (slice != 0 || e >= n) return;
     float s = 0.0f;
-    for (int b = 0; b < nblk; ++b) s += partial[(long)b * n + e];
+    for (int i = 0; i < 64; ++i) s += red[i][el];
     dw[e] += s;
 }
 
@@ -359,6 +381,18 @@ extern "C" int32_t pe_depthwise3x3_bwd_data_bf16(const void* dy, int32_t B, int3
                "%s: tensors must be 16-byte aligned", what);
     const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
     const long total = (long)B * H * W * (C / 8);
+    if (stride == 1) {
+        // stride 1: backward-data is the forward conv of dy with the mirrored filter, so it
+        // runs on the register-tiled forward kernel (float32 sum in mirrored tap order)
+        const int nty = dilation * (((H + dilation - 1) / dilation + DW_TY - 1) / DW_TY);
+        const int ntx = dilation * (((W + dilation - 1) / dilation + DW_TX - 1) / DW_TX);
+        const long threads = (long)B * nty * ntx * (C / 4);
+        PE_REQUIRE((threads + 255) / 256 < 0x7fffffffL, PE_E_UNSUPPORTED, "%s: grid too large", what);
+        depthwise3x3_s1_kernel<<<(unsigned)((threads + 255) / 256), 256, 0, as_stream(stream)>>>(
+            static_cast<const uint16_t*>(dy), B, H, W, C, dilation, static_cast<const uint16_t*>(w),
+            nullptr, nullptr, 0, static_cast<uint16_t*>(dx), nty, ntx, 1);
+        return check_launch(what);
+    }
     long blocks = (total + 255) / 256;
     if (blocks > 256 * 64) blocks = 256 * 64;
     depthwise3x3_bwd_data_kernel<<<(unsigned)blocks, 256, 0, as_stream(stream)>>>(
@@ -401,7 +435,7 @@ extern "C" int32_t pe_depthwise3x3_bwd_weight_bf16(const void* x, const void* dy
         dilation, Ho, Wo, cells, rl, static_cast<float*>(workspace));
     int32_t rc2 = check_launch(what);
     if (rc2 != PE_OK) return rc2;
-    depthwise3x3_bwd_weight_fold_kernel<<<(9 * C + 255) / 256, 256, 0, st>>>(
+    depthwise3x3_bwd_weight_fold_kernel<<<(9 * C + 3) / 4, 256, 0, st>>>(
         static_cast<const float*>(workspace), nblk, 9 * C, dw);
     return check_launch(what);
 }
@@ -433,7 +467,7 @@ extern "C" int32_t pe_depthwise3x3_fwd_bf16(const void* x, int32_t B, int32_t H,
         PE_REQUIRE((threads + 255) / 256 < 0x7fffffffL, PE_E_UNSUPPORTED, "%s: grid too large", what);
         depthwise3x3_s1_kernel<<<(unsigned)((threads + 255) / 256), 256, 0, as_stream(stream)>>>(
             static_cast<const uint16_t*>(x), B, H, W, C, dilation, static_cast<const uint16_t*>(w),
-            scale, shift, relu, static_cast<uint16_t*>(y), nty, ntx);
+            scale, shift, relu, static_cast<uint16_t*>(y), nty, ntx, 0);
         return check_launch(what);
     }
     long blocks = (total + 255) / 256;
