@@ -511,7 +511,7 @@ int32_t igemm_launch(const IgemmParams& pin, hipStream_t st, const char* what) {
     // tile choice: 128-pixel tiles unless they leave the chip under-filled; when even 64-pixel
     // tiles give fewer than two workgroups per CU, 64 x 64 tiles with the double-buffered
     // pipeline (each workgroup hides its own load latency) measured 15-25 % faster
-    int bn = p.N > 64 ? 128 : 64;
+    int bn = p.N > 64 ? 128 : (p.N > 32 ? 64 : 32);  // 32: the narrow branches of multi-branch nets
     const long ntn = (p.N + bn - 1) / bn;
     const long wg128 = ((maxM + 127) / 128) * ntn * p.nphase;
     int bm = (wg128 < 768 && maxM > 64) ? 64 : 128;
@@ -532,6 +532,8 @@ int32_t igemm_launch(const IgemmParams& pin, hipStream_t st, const char* what) {
     PE_CFG(128, 64, 2, false, false, 4)
     PE_CFG(64, 128, 2, false, false, 4)
     PE_CFG(64, 64, 2, false, false, 4)
+    PE_CFG(128, 32, 2, false, false, 4)
+    PE_CFG(64, 32, 2, false, false, 4)
     PE_CFG(128, 128, 2, false, true, 3)
     PE_CFG(128, 128, 2, false, true, 4)
     PE_CFG(128, 128, 2, true, true, 2)
