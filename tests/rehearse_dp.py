@@ -1,6 +1,6 @@
 """Rehearsal of the data-parallel training path on ONE GPU: two ranks share cuda:0 and exchange
 gradients through gloo (RCCL refuses two ranks per device).  Not collected by pytest; run as
-    python tests/rehearse_dp.py
+    python tests/rehearse_dp.py            (REH_MODEL=hrnet | mobilenet for the tape-graph networks)
 It checks that after a step both ranks hold identical parameters and that the averaged gradient
 equals the mean of the two ranks' local gradients.
 """
@@ -33,15 +33,38 @@ def worker(rank, world, port):
     from pose_estimation_amd.training import TrainablePoseResNet
 
     torch.cuda.set_device(0)
-    net = TrainablePoseResNet("cuda:0", layers=(1, 1, 1, 1))
-    net.load_state(pm.init_state(net.specs, seed=3))
-    net.enable_data_parallel(bucket_bytes=4 << 20)
-    log(rank, f"model built, {len(net.bucketer.buckets)} buckets")
+    which = os.environ.get("REH_MODEL", "resnet")
+    stride, sigma, radius = 4.0, 2.0, 6
+    if which == "hrnet":       # branched tape graph: layers finish out of arena order
+        from pose_estimation_amd import hrnet
+
+        net = hrnet.TrainablePoseHRNet("cuda:0", width=32, modules=(1, 1, 1), blocks=1,
+                                       layer1_blocks=1, sigma=sigma)
+        net.load_state(hrnet.init_state(net.spec, seed=3))
+        net.enable_data_parallel(bucket_bytes=1 << 20)
+    elif which == "mobilenet":
+        from pose_estimation_amd import mobilenet as mb
+
+        net = mb.TrainablePoseMobileNetV2("cuda:0", setting=mb.MBV2_SETTING[:4])
+        net.load_state(mb.init_state(net.blocks, 17, 0, seed=3))
+        net.enable_data_parallel(bucket_bytes=1 << 18)
+        stride, sigma, radius = 8.0, 1.0, 1
+    else:
+        net = TrainablePoseResNet("cuda:0", layers=(1, 1, 1, 1))
+        net.load_state(pm.init_state(net.specs, seed=3))
+        net.enable_data_parallel(bucket_bytes=4 << 20)
+    log(rank, f"{which} model built, {len(net.bucketer.buckets)} buckets")
     B, H, W = 4, 64, 64
     img = torch.from_numpy(synthetic.images_u8(B, H, W, seed=10 + rank)).cuda()
     joints = torch.from_numpy(synthetic.joints(B, 17, H, W, seed=20 + rank)).cuda()
 
     from pose_estimation_amd import ops
+
+    def backward(grad):
+        if which == "resnet":
+            net.backward(grad)
+        else:
+            net.backward({"final" if which == "hrnet" else "heat": grad})
 
     if os.environ.get("REH_STEPS_ONLY") == "1":
         for i in range(3):
@@ -53,15 +76,15 @@ def worker(rank, world, port):
     # local gradient without exchange, for the check
     bucketer, net.bucketer = net.bucketer, None
     hm = net.forward_train(img)
-    _, _, g, _ = ops.mse_fwd_bwd(hm, joints=joints, stride=4.0, sigma=2.0, radius=6)
-    net.backward(g)
+    _, _, g, _ = ops.mse_fwd_bwd(hm, joints=joints, stride=stride, sigma=sigma, radius=radius)
+    backward(g)
     local = net.grads.clone()
     net.bucketer = bucketer
     log(rank, "local gradient done")
 
     hm = net.forward_train(img)
-    _, _, g, _ = ops.mse_fwd_bwd(hm, joints=joints, stride=4.0, sigma=2.0, radius=6)
-    net.backward(g)
+    _, _, g, _ = ops.mse_fwd_bwd(hm, joints=joints, stride=stride, sigma=sigma, radius=radius)
+    backward(g)
     log(rank, "backward with bucketed all-reduce issued")
     net.bucketer.finish()
     torch.cuda.synchronize()
