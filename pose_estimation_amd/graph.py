@@ -165,6 +165,8 @@ class TrainGraph:
         # weight gradients depend only on a layer's input and its output gradient and nothing
         # reads them before the optimizer: they run beside the backward-data chain
         self.wgrad_stream: Optional[torch.cuda.Stream] = torch.cuda.Stream(device=dev)
+        self._keep: list = []
+        self._step_graphs: Dict[tuple, "StepGraph"] = {}
 
     # ------------------------------------------------------------------ parameters
     def view(self, arena: torch.Tensor, name: str) -> torch.Tensor:
@@ -320,15 +322,16 @@ class TrainGraph:
     @contextmanager
     def _beside(self, *tensors: torch.Tensor):
         """Launches inside run on the weight-gradient stream, after everything queued on the
-        current stream so far.  `tensors` are what those launches read: the caching allocator is
-        told not to hand their memory out again before the side stream is done with it."""
+        current stream so far.  `tensors` are what those launches read: they are kept alive until
+        backward has joined the two streams again, so the allocator cannot hand their memory to
+        a later launch on the main stream while the side stream still reads it (this also holds
+        under HIP-graph capture, where per-tensor stream bookkeeping is not available)."""
         side = self.wgrad_stream
         if side is None:
             yield
             return
         side.wait_stream(torch.cuda.current_stream(self.device))
-        for t in tensors:
-            t.record_stream(side)
+        self._keep.extend(tensors)
         with torch.cuda.stream(side):
             yield
 
@@ -419,6 +422,25 @@ class TrainGraph:
                 out.grad = None
         if self.wgrad_stream is not None:   # the optimizer reads every gradient
             torch.cuda.current_stream(self.device).wait_stream(self.wgrad_stream)
+        self._keep.clear()
+
+    # ------------------------------------------------------------------ HIP-graph replay
+    def replay(self, fn, *inputs: Optional[torch.Tensor]):
+        """Runs fn(*inputs) (a forward + loss + backward pass made of launches on the current
+        stream and the weight-gradient stream) as one HIP graph: captured the first time a given
+        set of input shapes is seen, replayed afterwards with the inputs copied into the
+        buffers it was captured on.  A branched network issues thousands of small launches per
+        step and the host cannot enqueue them as fast as the GPU runs them; a replay is one
+        launch.  Returns fn's outputs, which live in the graph's own memory and are overwritten
+        by the next replay.  Not available with a gradient exchange attached (the collectives
+        are issued by the host)."""
+        if self.bucketer is not None:
+            raise RuntimeError("HIP-graph replay and the bucketed gradient exchange are exclusive")
+        key = (fn.__name__,) + tuple(None if t is None else (tuple(t.shape), t.dtype) for t in inputs)
+        g = self._step_graphs.get(key)
+        if g is None:
+            g = self._step_graphs[key] = StepGraph(self, fn, inputs)
+        return g(*inputs)
 
     # ------------------------------------------------------------------ optimizer
     def optimizer_step(self, lr: float, optimizer: str = "adam", beta1: float = 0.9,
@@ -437,3 +459,32 @@ class TrainGraph:
         else:
             raise ValueError(f"unknown optimizer {optimizer!r}")
         self.refresh_transposes()
+
+
+class StepGraph:
+    """One captured pass of a TrainGraph (see TrainGraph.replay)."""
+
+    def __init__(self, net: TrainGraph, fn, example_inputs):
+        dev = net.device
+        self.static_in = [None if t is None else t.clone() for t in example_inputs]
+        # One pass outside capture: one-time set-up (workspace growth, kernel attributes, the
+        # allocator's pools) must not happen while capturing.  Running statistics stay frozen.
+        momentum, net.bn_momentum = net.bn_momentum, 0.0
+        cur = torch.cuda.current_stream(dev)
+        warm = torch.cuda.Stream(device=dev)
+        warm.wait_stream(cur)
+        with torch.cuda.stream(warm):
+            fn(*self.static_in)
+        cur.wait_stream(warm)
+        net.bn_momentum = momentum
+        torch.cuda.synchronize(dev)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.static_out = fn(*self.static_in)
+
+    def __call__(self, *inputs):
+        for dst, src in zip(self.static_in, inputs):
+            if dst is not None:
+                dst.copy_(src)
+        self.graph.replay()
+        return self.static_out

@@ -295,13 +295,12 @@ class TrainablePoseMobileNetV2(TrainGraph):
         after training steps)."""
         return self.forward(pnn.preprocess_u8(images_u8), False)
 
-    def train_step(self, images_u8, joints: torch.Tensor, mask: Optional[torch.Tensor] = None,
-                   lr: float = 1e-3, optimizer: str = "adam", beta1: float = 0.9,
-                   beta2: float = 0.999, eps: float = 1e-8, momentum: float = 0.9,
-                   x_s2d: Optional[torch.Tensor] = None):
-        """One optimisation step on heat-map loss + vector-map loss; returns
-        (loss [1] device tensor, per_joint [K])."""
-        out = self.forward_train(images_u8, x_s2d)
+    def _pass_u8(self, images_u8, joints, mask):
+        return self._pass(pnn.preprocess_u8(images_u8), joints, mask)
+
+    def _pass(self, x_s2d, joints, mask):
+        """Forward with batch statistics, both losses, backward: fills the gradient arena."""
+        out = self.forward(x_s2d, True)
         heat = out[0] if self.num_pairs else out
         s = float(self.output_stride)
         loss, per_joint, grad, _ = ops.mse_fwd_bwd(heat, joints=joints, mask=mask, stride=s,
@@ -313,5 +312,19 @@ class TrainablePoseMobileNetV2(TrainGraph):
             grads["vec"] = vgrad
             loss = loss + vloss
         self.backward(grads)
+        return loss, per_joint
+
+    def train_step(self, images_u8, joints: torch.Tensor, mask: Optional[torch.Tensor] = None,
+                   lr: float = 1e-3, optimizer: str = "adam", beta1: float = 0.9,
+                   beta2: float = 0.999, eps: float = 1e-8, momentum: float = 0.9,
+                   x_s2d: Optional[torch.Tensor] = None, hip_graph: bool = False):
+        """One optimisation step on heat-map loss + vector-map loss; returns
+        (loss [1] device tensor, per_joint [K]).  hip_graph: replay the forward/loss/backward
+        pass as one captured HIP graph (see TrainGraph.replay)."""
+        fn, x = (self._pass, x_s2d) if x_s2d is not None else (self._pass_u8, images_u8)
+        if hip_graph:
+            loss, per_joint = self.replay(fn, x, joints, mask)
+        else:
+            loss, per_joint = fn(x, joints, mask)
         self.optimizer_step(lr, optimizer, beta1, beta2, eps, momentum)
         return loss, per_joint

@@ -209,3 +209,25 @@ def test_trainer_builds_and_steps_the_hrnet_backbone():
     hm = tr.predict(feats["images"])
     xy, conf, idx = tr.decode(hm)
     assert tuple(hm.shape) == (4, 17, 32, 24) and tuple(xy.shape) == (4, 17, 2)
+
+
+def test_hip_graph_replay_repeats_the_eager_steps_bit_for_bit():
+    """The captured forward/loss/backward pass replays the same kernels in the same order: the
+    loss trajectory and the parameters equal the eager run's exactly; running statistics too
+    (the warm-up pass before capture leaves them untouched)."""
+    B, H, W = 4, 64, 64
+    runs = []
+    for use_graph in (False, True):
+        net, state, img, joints, mask = make_case(B, H, W, seed=29)
+        jt = torch.from_numpy(joints).cuda()
+        mt = torch.from_numpy(mask).cuda()
+        losses = []
+        for i in range(5):
+            it = torch.from_numpy(synthetic.images_u8(B, H, W, seed=40 + i)).cuda()   # new data every step
+            loss, _ = net.train_step(it, jt, mt, lr=1e-3, hip_graph=use_graph)
+            losses.append(loss.item())
+        runs.append((losses, net.master.clone(), net.bn_mean["stem.conv2"].clone()))
+    assert len(net._step_graphs) == 1
+    assert runs[0][0] == runs[1][0]
+    assert torch.equal(runs[0][1], runs[1][1])
+    assert torch.equal(runs[0][2], runs[1][2])
