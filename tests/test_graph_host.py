@@ -1,0 +1,84 @@
+"""Host-side logic of the tape-graph networks that needs no GPU: layer lists, packed layouts,
+parameter masks, channel padding, and the narrow backward-data weight layout the library
+reports (a host-only entry point of the C ABI)."""
+import pytest
+import torch
+
+from pose_estimation_amd import hrnet
+from pose_estimation_amd import mobilenet as mb
+from pose_estimation_amd import nn as pnn
+from pose_estimation_amd.graph import Layer
+
+
+def test_narrow_backward_data_layout_is_a_valid_run_packing():
+    """Every tap gets a (slot, sub-block) of its own; taps sharing a slot read adjacent gradient
+    columns of one input-parity class and one filter row, in ascending column order."""
+    for k, s, p, cout in [(3, 1, 1, 32), (3, 2, 1, 32), (1, 1, 0, 32), (3, 1, 1, 16), (3, 2, 1, 8),
+                          (5, 1, 2, 16), (7, 2, 3, 8)]:
+        slot, sub, n = pnn.narrow_bwd_layout(k, s, p, cout)
+        P = 64 // cout
+        assert len(set(zip(slot, sub))) == k * k and max(slot) == n - 1 and max(sub) < P
+        for q in range(n):
+            taps = [(kh, kw) for kh in range(k) for kw in range(k) if slot[kh * k + kw] == q]
+            assert len({kh for kh, _ in taps}) == 1
+            kh = taps[0][0]
+            cols = {}
+            for _, kw in taps:
+                px = (kw - p) % s
+                assert (px + p - kw) % s == 0
+                cols[sub[kh * k + kw]] = ((px + p - kw) // s, px)
+            start = cols[0][0]
+            assert len({px for _, px in cols.values()}) == 1          # one parity class
+            assert all(col == start + j for j, (col, _) in cols.items())
+    # 3x3 stride 1 on 32 channels: 6 slots of 64 instead of 9 taps padded to 64 channels
+    assert pnn.narrow_bwd_layout(3, 1, 1, 32)[2] == 6
+    assert pnn.bwd_data_weight_shape(64, 32, 3, 1, 1) == (64, 6, 64)
+    assert pnn.bwd_data_weight_shape(32, 64, 3, 1, 1) == (32, 9, 64)
+
+
+def test_layer_packings_and_masks():
+    g = torch.Generator().manual_seed(1)
+    L = Layer("a", "conv", 32, 64, 3, 1, 1)
+    assert L.narrow and L.packed_shape() == (64, 3, 2, 64)
+    w = torch.randn(64, 32, 3, 3, generator=g)
+    p = L.pack(w)
+    assert p.dtype == torch.float32 and tuple(p.shape) == L.packed_shape()
+    m = L.param_mask()
+    assert m.sum().item() == w.numel() and torch.equal(p * m, p)
+    assert torch.equal(p.to(torch.bfloat16), pnn.pack_conv_weight_narrow(w))
+    assert Layer("b", "conv", 64, 64, 3).param_mask() is None
+    S = Layer("s", "stem3", 3, 64, 3, 2, 2)
+    assert S.packed_shape() == (64, 2, 64) and S.param_mask().sum().item() == 64 * 27
+    D = Layer("d", "dw", 128, 128, 3, 2, 2, 1)
+    wd = torch.randn(128, 1, 3, 3, generator=g)
+    assert D.packed_shape() == (9, 128) and not D.narrow
+    assert torch.equal(D.pack(wd)[4], wd[:, 0, 1, 1])
+    H = Layer("h", "head", 32, 17)
+    assert H.narrow and H.packed_shape() == (17, 1, 1, 64) and H.kpad == 64
+    assert Layer("v", "head", 320, 76).kpad == 128
+
+
+def test_hrnet_graph_layers_follow_execution_order():
+    spec = hrnet.hrnet_specs()
+    layers = hrnet._graph_layers(spec)
+    assert [L.name for L in layers[:-1]] == [u.name for u in hrnet.all_units(spec)]
+    assert layers[0].kind == "stem3" and layers[-1].kind == "head" and layers[-1].cin == 32
+    assert sum(L.narrow for L in layers) == 90
+    # every stride-2 chain out of the 32-channel branch starts with a narrow-input conv
+    assert all(L.narrow for L in layers if ".fuse" in L.name and L.cin == 32)
+
+
+def test_mobilenet_channel_padding():
+    blocks = mb.mobilenet_v2_specs()
+    layers = mb._graph_layers(blocks, 17, 19)
+    assert all(L.cout % 64 == 0 for L in layers if L.kind != "head")
+    assert [L.name for L in layers[-2:]] == ["heat", "vec"] and layers[-1].cout == 76
+    st = mb.init_state(blocks, 17, 19, seed=3)
+    ps = mb.pad_state(layers, st)
+    w, wp = st["block1.project.weight"], ps["block1.project.weight"]
+    assert tuple(wp.shape) == (64, 128, 1, 1)
+    assert torch.equal(wp[:24, :96], w) and not wp[24:].any() and not wp[:, 96:].any()
+    assert ps["block1.project.bn.gamma"][24:].abs().sum() == 0     # padded norms are switched off
+    assert torch.equal(ps["block1.dw.weight"][:96], st["block1.dw.weight"])
+    with pytest.raises(KeyError):
+        mb.pad_state(layers, {})
