@@ -465,6 +465,25 @@ int32_t pe_fuse_upsample_add_bwd_bf16(const void* dy, const void* y, int32_t n_l
 int32_t pe_add_bf16(const void* a, const void* b, int64_t n, void* out, pe_stream_t stream);
 
 /* ------------------------------------------------------------------------
+ * Gradient exchange without a host framework (one communicator per process / GPU).
+ * Replaces: Horovod's allreduce (test.ipynb:12).  RCCL is loaded on first use; the calls return
+ * PE_E_UNSUPPORTED when it cannot be.
+ *   pe_comm_unique_id  : one rank makes the 128-byte id and hands it to the others by
+ *                        whatever channel launched them.
+ *   pe_comm_create     : collective over `world` ranks, on the caller's current GPU.
+ *   pe_allreduce_bucket: buf[0..n) = scale * sum over ranks of buf, in place, asynchronous on
+ *                        `stream` (scale = 1/world averages; dtype PE_DTYPE_F32 / PE_DTYPE_BF16).
+ * The Python layer uses torch.distributed (the same RCCL) by default; these are for consumers
+ * that have no such layer.
+ * ---------------------------------------------------------------------- */
+typedef struct pe_comm pe_comm;
+int32_t pe_comm_unique_id(uint8_t id[128]);
+int32_t pe_comm_create(int32_t rank, int32_t world, const uint8_t id[128], pe_comm** out);
+int32_t pe_allreduce_bucket(pe_comm* comm, void* buf, int64_t n, int32_t dtype, float scale,
+                            pe_stream_t stream);
+int32_t pe_comm_destroy(pe_comm* comm);
+
+/* ------------------------------------------------------------------------
  * Detection branch: per-anchor targets from ground-truth boxes, and the loss on them.
  * Replaces: utils/bboxes.py (PoseEstimation.pyproj:35; absent).  Visible in the reference: 1500 =
  * 20*20*3 + 10*10*3 anchors per image with `classes`, `weights`, `regs` labels

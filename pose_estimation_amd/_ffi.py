@@ -158,6 +158,10 @@ SIGNATURES = {
         c_int32, [c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_int32, c_int32,
                   c_int32, c_void_p, c_void_p]),
     "pe_add_bf16": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p, c_void_p]),
+    "pe_comm_unique_id": (c_int32, [c_void_p]),
+    "pe_comm_create": (c_int32, [c_int32, c_int32, c_void_p, c_void_p]),
+    "pe_allreduce_bucket": (c_int32, [c_void_p, c_void_p, c_int64, c_int32, c_float, c_void_p]),
+    "pe_comm_destroy": (c_int32, [c_void_p]),
     "pe_depthwise3x3_bwd_data_bf16": (
         c_int32, [c_void_p] + [c_int32] * 6 + [c_void_p, c_void_p, c_void_p]),
     "pe_depthwise3x3_bwd_weight_workspace_bytes": (c_size_t, [c_int32]),

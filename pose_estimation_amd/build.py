@@ -79,7 +79,7 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     if force or not LIB.exists() or any(o.stat().st_mtime > LIB.stat().st_mtime for o in objs):
         cmd = [_hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", str(LIB)] + [
             str(o) for o in objs
-        ]
+        ] + ["-ldl"]
         if verbose:
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)

@@ -95,3 +95,52 @@ class GradBucketer:
         for (start, _end) in self.buckets:
             self.layer_done(start)
         self.finish()
+
+
+class NativeComm:
+    """The library's own RCCL communicator (pe_comm_*): the route for hosts without
+    torch.distributed.  rank 0 makes `unique_id()` and the launcher hands the 128 bytes to the
+    other ranks; every rank then constructs NativeComm(rank, world, id) with its GPU current."""
+
+    def __init__(self, rank: int, world: int, unique_id: bytes):
+        import ctypes
+
+        from ._ffi import check, lib
+
+        if len(unique_id) != 128:
+            raise ValueError("unique_id must be 128 bytes")
+        self._lib, self._check = lib(), check
+        self.rank, self.world = rank, world
+        buf = (ctypes.c_uint8 * 128).from_buffer_copy(unique_id)
+        self._h = ctypes.c_void_p()
+        check(self._lib.pe_comm_create(rank, world, ctypes.addressof(buf), ctypes.byref(self._h)))
+
+    @staticmethod
+    def unique_id() -> bytes:
+        import ctypes
+
+        from ._ffi import check, lib
+
+        buf = (ctypes.c_uint8 * 128)()
+        check(lib().pe_comm_unique_id(ctypes.addressof(buf)))
+        return bytes(buf)
+
+    def all_reduce_(self, t: torch.Tensor, scale: float = 1.0) -> torch.Tensor:
+        """t = scale * sum over ranks of t, in place, asynchronous on torch's current stream."""
+        if not t.is_cuda or not t.is_contiguous() or t.dtype not in (torch.float32, torch.bfloat16):
+            raise ValueError("all_reduce_: contiguous float32 / bfloat16 GPU tensor")
+        dt = 0 if t.dtype == torch.float32 else 1
+        self._check(self._lib.pe_allreduce_bucket(self._h, t.data_ptr(), t.numel(), dt, float(scale),
+                                                  torch.cuda.current_stream(t.device).cuda_stream))
+        return t
+
+    def close(self) -> None:
+        if self._h:
+            self._lib.pe_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -91,3 +91,27 @@ def test_bucketed_allreduce_two_ranks_gloo():
     assert sorted(r[0] for r in results) == [0, 1]
     assert all(r[1] for r in results), "bucketed all-reduce differs from the sum over ranks"
     assert all(r[2] >= 3 for r in results)
+
+
+@pytest.mark.gpu
+def test_native_rccl_communicator_single_rank():
+    """pe_comm_* over RCCL with one rank (a one-GPU box cannot hold two): the all-reduce is the
+    identity and the folded scale is applied, for both transport dtypes."""
+    import torch
+
+    from pose_estimation_amd.parallel import NativeComm
+
+    torch.cuda.set_device(0)
+    uid = NativeComm.unique_id()
+    assert len(uid) == 128 and any(uid)
+    comm = NativeComm(0, 1, uid)
+    g = torch.Generator().manual_seed(3)
+    a = torch.randn(100003, generator=g).cuda()
+    want = a * 0.25
+    comm.all_reduce_(a, scale=0.25)
+    b = torch.randn(4096, generator=g).to(torch.bfloat16).cuda()
+    wantb = b.clone()
+    comm.all_reduce_(b)
+    torch.cuda.synchronize()
+    assert torch.equal(a, want) and torch.equal(b, wantb)
+    comm.close()
