@@ -166,6 +166,7 @@ class TrainGraph:
         # reads them before the optimizer: they run beside the backward-data chain
         self.wgrad_stream: Optional[torch.cuda.Stream] = torch.cuda.Stream(device=dev)
         self._keep: list = []
+        self._pending_wg: list = []
         self._step_graphs: Dict[tuple, "StepGraph"] = {}
 
     # ------------------------------------------------------------------ parameters
@@ -350,19 +351,33 @@ class TrainGraph:
             return
         v.grad = g if v.grad is None else pnn.add_bf16(v.grad, g)
 
+    WGRAD_BATCH = 8   # weight gradients handed to the side stream per fork
+
     def _weight_grad(self, L: Layer, x: torch.Tensor, dz: torch.Tensor, cout=None) -> None:
-        gw = self._g(L.name + ".weight")
-        with self._beside(x, dz):
-            if L.kind == "stem3":
-                pnn.stem3x3s2_bwd_weight(x, dz, gw)
-            elif L.kind == "dw":
-                pnn.depthwise3x3_bwd_weight(x, dz, gw, L.stride, L.dilation)
-            else:
-                pnn.conv2d_bwd_weight(x, dz, gw, L.k, L.stride, L.pad, cout=cout)
-            m = self.masks.get(L.name)
-            if m is not None:
-                pnn.mul_(gw, m)
-            self._done(L)
+        """Queues a layer's weight gradient.  Forking to the side stream costs the host an event
+        record, a wait and two stream switches; done per layer that is a third of the time it
+        takes to enqueue a step of a 300-layer network, so the forks are batched."""
+        self._pending_wg.append((L, x, dz, cout))
+        if len(self._pending_wg) >= self.WGRAD_BATCH:
+            self._flush_weight_grads()
+
+    def _flush_weight_grads(self) -> None:
+        if not self._pending_wg:
+            return
+        pending, self._pending_wg = self._pending_wg, []
+        with self._beside(*[t for (_, x, dz, _) in pending for t in (x, dz)]):
+            for L, x, dz, cout in pending:
+                gw = self._g(L.name + ".weight")
+                if L.kind == "stem3":
+                    pnn.stem3x3s2_bwd_weight(x, dz, gw)
+                elif L.kind == "dw":
+                    pnn.depthwise3x3_bwd_weight(x, dz, gw, L.stride, L.dilation)
+                else:
+                    pnn.conv2d_bwd_weight(x, dz, gw, L.k, L.stride, L.pad, cout=cout)
+                m = self.masks.get(L.name)
+                if m is not None:
+                    pnn.mul_(gw, m)
+                self._done(L)
 
     def _data_grad(self, L: Layer, x: Var, dz: torch.Tensor) -> None:
         if not x.needs_grad:
@@ -420,6 +435,7 @@ class TrainGraph:
                 if L.kind != "stem3":
                     self._data_grad(L, x, dz)
                 out.grad = None
+        self._flush_weight_grads()
         if self.wgrad_stream is not None:   # the optimizer reads every gradient
             torch.cuda.current_stream(self.device).wait_stream(self.wgrad_stream)
         self._keep.clear()
