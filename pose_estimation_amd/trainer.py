@@ -97,9 +97,15 @@ class Trainer:
             img = torch.from_numpy(synthetic.images_u8(B, H, W, seed + 1)).to(self.device)
             joints = torch.from_numpy(synthetic.joints(B, K, H, W, seed + 2)).to(self.device)
             mask = torch.from_numpy(synthetic.ignore_mask(B, H // s, W // s, seed + 4)).to(self.device)
-            hm, w = ops.render_targets(joints, H // s, W // s, float(s), sigma, layout="NHWC")
-            yield ({"images": img},
-                   {"heatmaps": hm, "masks": mask, "joints": joints, "weights": w})
+            radius = self.model_cfg.get("radius")
+            hm, w = ops.render_targets(joints, H // s, W // s, float(s), sigma,
+                                       None if radius is None else int(radius), layout="NHWC")
+            labels = {"heatmaps": hm, "masks": mask, "joints": joints, "weights": w}
+            pairs = self.model_cfg.get("pairs")
+            if pairs:   # the reference's second dense label (test.ipynb:925-944)
+                labels["vecmaps"] = ops.render_vecmaps(joints, [tuple(p) for p in pairs], H // s,
+                                                       W // s, float(s), layout="NHWC")
+            yield ({"images": img}, labels)
             i += 1
 
     # ------------------------------------------------------------------ per-batch calls

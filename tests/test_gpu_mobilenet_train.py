@@ -174,3 +174,32 @@ def test_full_network_step_runs_at_320x320():
     assert torch.isfinite(net.master).all()
     heat, vec = net.predict(img)
     assert tuple(heat.shape) == (4, 17, 40, 40) and tuple(vec.shape) == (4, 76, 40, 40)
+
+
+def test_trainer_with_the_mobilenet_backbone(tmp_path):
+    """The reference's configuration shape: MobileNetV2, stride-8 labels with 3x3 supports,
+    heat maps + vector maps in the batch dict, checkpoint round trip."""
+    from pose_estimation_amd import Trainer
+
+    cfg = {"model_config": {"backbone": "mobilenet_v2", "heatmap_stride": 8, "sigma": 1.0,
+                            "radius": 1, "pairs": [list(p) for p in PAIRS]},
+           "train_config": {"batch_size": 4, "preprocess": {"image_resize": [96, 64]}}}
+    tr = Trainer(cfg, device="cuda:0")
+    tr.build_model(seed=5)
+    feats, labels = next(iter(tr.get_features_labels_data(num_batches=1)))
+    assert tuple(labels["heatmaps"].shape) == (4, 12, 8, 17)
+    assert tuple(labels["vecmaps"].shape) == (4, 12, 8, 4 * len(PAIRS))
+    losses = [tr.train_step(feats, labels).item() for _ in range(6)]
+    assert np.isfinite(losses).all() and losses[-1] < losses[0]
+    heat, vec = tr.predict(feats["images"])
+    assert tuple(heat.shape) == (4, 17, 12, 8) and tuple(vec.shape) == (4, 4 * len(PAIRS), 12, 8)
+    path = str(tmp_path / "mb.pt")
+    tr.save(path)
+    tr2 = Trainer(cfg, device="cuda:0")
+    tr2.build_model(seed=99)
+    tr2.load(path)
+    assert torch.equal(tr2.net.master, tr.net.master)
+    h2, v2 = tr2.predict(feats["images"])
+    assert torch.equal(h2, heat) and torch.equal(v2, vec)
+    # one more step on both: identical trajectories after the round trip
+    assert tr.train_step(feats, labels).item() == tr2.train_step(feats, labels).item()
