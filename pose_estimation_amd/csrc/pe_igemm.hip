@@ -19,9 +19,9 @@
 //
 // The MFMA "A" operand is the weight tile and the "B" operand the activation tile, so a lane's
 // four accumulator registers are four consecutive output channels of one pixel.  The epilogue
-// (scale, shift, residual, ReLU, bf16 convert) stages the fp32 tile through LDS in two column
-// halves so that residual loads and output stores are whole 16-byte chunks, BN bytes contiguous
-// per pixel.
+// (scale, shift, residual, ReLU, bf16 convert) stages the fp32 tile through LDS in two row
+// halves so that residual loads and output stores are whole 16-byte chunks, 2 * BN bytes
+// contiguous per pixel.
 //
 // Several "phases" (output-parity classes of a stride-2 transposed conv or of a stride-2
 // backward-data pass) run in one launch along gridDim.y, each with its own taps, weight block,
@@ -250,58 +250,68 @@ __attribute__((amdgpu_waves_per_eu(MINB * WM / 2, MINB * WM / 2))) void igemm_ke
     const int nq = (lane >> 4) * 4;
 
     if (p.out_mode == 0 && (p.N & 7) == 0 && (p.ldc & 7) == 0) {
-        constexpr int HALF = BN / 2;    // columns staged per pass (one wave_n half)
-        constexpr int CP = HALF + 4;    // float pitch: 8-lane ds_write_b128 groups hit distinct banks
-        constexpr int CPR = HALF / 8;   // 16-byte output chunks per pixel row
-        constexpr int RPP = NT / CPR;   // pixel rows per pass of the store loop
-        constexpr int NPASS = (BM + RPP - 1) / RPP;
+        // The fp32 tile goes through LDS in two ROW halves (the wave_m halves), so that every
+        // store and residual load of a pixel covers the tile's full BN-channel run (256
+        // contiguous bytes at BN = 128) instead of half of it.
+        constexpr int RH = BM / 2;      // rows staged per pass
+        constexpr int CP = BN + 4;      // float pitch: 8-lane ds_write_b128 groups hit distinct banks
+        constexpr int CPR = BN / 8;     // 16-byte output chunks per pixel row
+        constexpr int RPP = NT / CPR;   // pixel rows per iteration of the store loop
+        constexpr int NPASS = (RH + RPP - 1) / RPP;
+        constexpr int SG = NT / BN;     // statistics: thread groups over rows
+        constexpr int RPG = RH / SG;    // rows per group and pass
+        static_assert(SG >= 1 && RPG >= 1, "tile too small for the statistics fold");
         float* cs = reinterpret_cast<float*>(smem);
+        float* sred = cs + RH * CP;     // [SG][2][BN]
         const int chunk = tid % CPR;
         const int prow = tid / CPR;
-        // output pixel of each store pass (the same for both column halves); -1 = no store
-        long opixs[NPASS];
-#pragma unroll
-        for (int pass = 0; pass < NPASS; ++pass) {
-            const int pr = prow + pass * RPP;
-            const long m = m0 + pr;
-            long opix = m;
-            if (!identity) {
-                int bb, rem, oy, ox;
-                fast_divmod((int)(m < M ? m : 0), HoWo, inv_howo, bb, rem);
-                fast_divmod(rem, Wo, inv_wo, oy, ox);
-                opix = (long)bb * OHW + (oy * p.osy + ooy) * p.OW + ox * p.osx + oox;
-            }
-            opixs[pass] = (pr < BM && m < M) ? opix : -1;
-        }
+        const int n = n0 + chunk * 8;
+        const int scol = tid % BN, sgrp = tid / BN;
+        float st1 = 0.0f, st2 = 0.0f;   // running column sums of the fused statistics
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
-            // the residual rows of every pass are requested before the tile is staged, so the
-            // loads are in flight across the LDS round trip instead of one per pass
-            const int nres = n0 + half * HALF + chunk * 8;
+            // output pixel of each store iteration; -1 = no store
+            long opixs[NPASS];
+#pragma unroll
+            for (int pass = 0; pass < NPASS; ++pass) {
+                const int pr = prow + pass * RPP;
+                const long m = m0 + half * RH + pr;
+                long opix = m;
+                if (!identity) {
+                    int bb, rem, oy, ox;
+                    fast_divmod((int)(m < M ? m : 0), HoWo, inv_howo, bb, rem);
+                    fast_divmod(rem, Wo, inv_wo, oy, ox);
+                    opix = (long)bb * OHW + (oy * p.osy + ooy) * p.OW + ox * p.osx + oox;
+                }
+                opixs[pass] = (pr < RH && m < M) ? opix : -1;
+            }
+            // the residual rows of every iteration are requested before the tile is staged, so
+            // the loads are in flight across the LDS round trip instead of one per iteration
             uint4 rres[NPASS];
             if (p.res) {
 #pragma unroll
                 for (int pass = 0; pass < NPASS; ++pass) {
                     rres[pass] = make_uint4(0u, 0u, 0u, 0u);
-                    if (opixs[pass] >= 0 && nres < p.N)
+                    if (opixs[pass] >= 0 && n < p.N)
                         rres[pass] =
-                            *reinterpret_cast<const uint4*>(p.res + opixs[pass] * p.ldc + nres);
+                            *reinterpret_cast<const uint4*>(p.res + opixs[pass] * p.ldc + n);
                 }
             }
-            if (wave_n == half) {
+            if (wave_m / (WM / 2) == half) {
+                const int rbase = (wave_m % (WM / 2)) * WROWS;
 #pragma unroll
                 for (int a = 0; a < TN; ++a) {
-                    const int col = a * 16 + nq;
-                    const int n = n0 + half * HALF + col;
+                    const int col = wave_n * (BN / 2) + a * 16 + nq;
+                    const int nn = n0 + col;
                     if (p.scale || p.shift) {  // uniform: training convs carry neither
                         f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
-                        if (n < p.N) {
-                            if (p.scale) sc = *reinterpret_cast<const f32x4*>(p.scale + n);
-                            if (p.shift) sh = *reinterpret_cast<const f32x4*>(p.shift + n);
+                        if (nn < p.N) {
+                            if (p.scale) sc = *reinterpret_cast<const f32x4*>(p.scale + nn);
+                            if (p.shift) sh = *reinterpret_cast<const f32x4*>(p.shift + nn);
                         }
 #pragma unroll
                         for (int b = 0; b < TM; ++b) {
-                            const int pr = wave_m * WROWS + b * 16 + lr;
+                            const int pr = rbase + b * 16 + lr;
                             f32x4 v;  // one fused multiply-add per element
                             v.x = fmaf(acc[a][b].x, sc.x, sh.x);
                             v.y = fmaf(acc[a][b].y, sc.y, sh.y);
@@ -312,14 +322,13 @@ __attribute__((amdgpu_waves_per_eu(MINB * WM / 2, MINB * WM / 2))) void igemm_ke
                     } else {
 #pragma unroll
                         for (int b = 0; b < TM; ++b) {
-                            const int pr = wave_m * WROWS + b * 16 + lr;
+                            const int pr = rbase + b * 16 + lr;
                             *reinterpret_cast<f32x4*>(cs + pr * CP + col) = acc[a][b];
                         }
                     }
                 }
             }
             __syncthreads();
-            const int n = n0 + half * HALF + chunk * 8;
             if (n < p.N) {
 #pragma unroll
                 for (int pass = 0; pass < NPASS; ++pass) {
@@ -357,29 +366,27 @@ __attribute__((amdgpu_waves_per_eu(MINB * WM / 2, MINB * WM / 2))) void igemm_ke
             // Batch-norm statistics of what was just stored (the bf16-rounded tile): per column,
             // sum and sum of squares over the tile's rows, in a fixed order.  Rows past M hold
             // exact zeros (their inputs were the zero block and a BN conv has no bias).
-            constexpr int SG = NT / HALF;   // thread groups over rows
-            constexpr int RPG = BM / SG;    // rows per group
-            float* sred = cs + BM * CP;     // [SG][2][HALF]
             if (p.stat_partial) {
-                const int colh = tid % HALF, grp = tid / HALF;
-                float s1 = 0.0f, s2 = 0.0f;
 #pragma unroll 8
-                for (int r = grp * RPG; r < (grp + 1) * RPG; ++r) {
+                for (int r = sgrp * RPG; r < (sgrp + 1) * RPG; ++r) {
                     const float v =
-                        __uint_as_float(pack_bf16x2_bits(cs[r * CP + colh], 0.0f) << 16);
-                    s1 += v;
-                    s2 += v * v;
+                        __uint_as_float(pack_bf16x2_bits(cs[r * CP + scol], 0.0f) << 16);
+                    st1 += v;
+                    st2 += v * v;
                 }
-                sred[(grp * 2 + 0) * HALF + colh] = s1;
-                sred[(grp * 2 + 1) * HALF + colh] = s2;
             }
+            __syncthreads();  // the staged half is consumed before the next one overwrites it
+        }
+        if (p.stat_partial) {
+            sred[(sgrp * 2 + 0) * BN + scol] = st1;
+            sred[(sgrp * 2 + 1) * BN + scol] = st2;
             __syncthreads();
-            if (p.stat_partial && tid < 2 * HALF) {
-                const int sidx = tid / HALF, colh = tid % HALF;
+            for (int e = tid; e < 2 * BN; e += NT) {
+                const int sidx = e / BN, col = e % BN;
                 float t = 0.0f;
 #pragma unroll
-                for (int g2 = 0; g2 < SG; ++g2) t += sred[(g2 * 2 + sidx) * HALF + colh];
-                const int nn = n0 + half * HALF + colh;
+                for (int g2 = 0; g2 < SG; ++g2) t += sred[(g2 * 2 + sidx) * BN + col];
+                const int nn = n0 + col;
                 if (nn < p.N)
                     p.stat_partial[((long)(ph * p.stat_ntm + tile_m) * 2 + sidx) * p.N + nn] = t;
             }
@@ -423,7 +430,7 @@ template <int BM, int BN, bool DB>
 static constexpr size_t lds_bytes() {
     const size_t ktile = (size_t)(BM + BN) * ROWB * (DB ? 2 : 1);
     // epilogue half tile + the per-group column sums of the fused batch-norm statistics
-    const size_t etile = (size_t)BM * (BN / 2 + 4) * sizeof(float) + 2 * 512 * sizeof(float);
+    const size_t etile = (size_t)(BM / 2) * (BN + 4) * sizeof(float) + 2 * 512 * sizeof(float);
     return ktile > etile ? ktile : etile;
 }
 
