@@ -49,6 +49,7 @@ struct IgemmParams {
     long stat_capacity_rows;
     int32_t* stat_rows_out;   // host pointer
     int stat_ntm;             // filled in by igemm_launch
+    int nt_store;             // filled in by igemm_launch: non-temporal output stores
     int32_t tap_info[kMaxTaps];  // dy | dx << 8 | slot << 16, packed by igemm_launch for the kernel
     // Optional phases (gridDim.y): phase i uses taps [ph_t0[i], ph_t0[i] + ph_T[i]), the row grid
     // ph_Ho[i] x ph_Wo[i], output offset (ph_ooy[i], ph_oox[i]) and weights w + ph_woff[i].

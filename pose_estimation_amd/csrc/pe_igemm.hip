@@ -268,6 +268,8 @@ __attribute__((amdgpu_waves_per_eu(MINB * WM / 2, MINB * WM / 2))) void igemm_ke
         const int n = n0 + chunk * 8;
         const int scol = tid % BN, sgrp = tid / BN;
         float st1 = 0.0f, st2 = 0.0f;   // running column sums of the fused statistics
+        // outputs far larger than the caches are streamed past them (uniform)
+        const bool nt_store = p.nt_store != 0;
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             // output pixel of each store iteration; -1 = no store
@@ -292,9 +294,16 @@ __attribute__((amdgpu_waves_per_eu(MINB * WM / 2, MINB * WM / 2))) void igemm_ke
 #pragma unroll
                 for (int pass = 0; pass < NPASS; ++pass) {
                     rres[pass] = make_uint4(0u, 0u, 0u, 0u);
-                    if (opixs[pass] >= 0 && n < p.N)
-                        rres[pass] =
-                            *reinterpret_cast<const uint4*>(p.res + opixs[pass] * p.ldc + n);
+                    if (opixs[pass] >= 0 && n < p.N) {
+                        const uint16_t* src = p.res + opixs[pass] * p.ldc + n;
+                        if (nt_store) {   // as large as the output and read exactly once
+                            const u32x4 rv =
+                                __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(src));
+                            rres[pass] = make_uint4(rv.x, rv.y, rv.z, rv.w);
+                        } else {
+                            rres[pass] = *reinterpret_cast<const uint4*>(src);
+                        }
+                    }
                 }
             }
             if (wave_m / (WM / 2) == half) {
@@ -360,7 +369,13 @@ __attribute__((amdgpu_waves_per_eu(MINB * WM / 2, MINB * WM / 2))) void igemm_ke
                     o.y = pack_bf16x2(v[2], v[3]);
                     o.z = pack_bf16x2(v[4], v[5]);
                     o.w = pack_bf16x2(v[6], v[7]);
-                    *reinterpret_cast<uint4*>(reinterpret_cast<uint16_t*>(p.y) + opix * p.ldc + n) = o;
+                    uint16_t* dst = reinterpret_cast<uint16_t*>(p.y) + opix * p.ldc + n;
+                    if (nt_store) {
+                        const u32x4 ov = {o.x, o.y, o.z, o.w};
+                        __builtin_nontemporal_store(ov, reinterpret_cast<u32x4*>(dst));
+                    } else {
+                        *reinterpret_cast<uint4*>(dst) = o;
+                    }
                 }
             }
             // Batch-norm statistics of what was just stored (the bf16-rounded tile): per column,
@@ -515,6 +530,11 @@ int32_t igemm_launch(const IgemmParams& pin, hipStream_t st, const char* what) {
                    (long)p.B * p.OH * p.OW < 0x7fffffffL,
                PE_E_UNSUPPORTED, "%s: pixel count does not fit int32", what);
 
+    {
+        static const char* nts = getenv("PE_IGEMM_NT_MB");  // tuning aid: threshold in MB, 0 = off
+        const long thr = nts ? atol(nts) : 64;
+        p.nt_store = thr > 0 && (long)p.B * p.OH * p.OW * p.ldc * 2 >= thr * 1000000L;
+    }
     // tile choice: 128-pixel tiles unless they leave the chip under-filled; when even 64-pixel
     // tiles give fewer than two workgroups per CU, 64 x 64 tiles with the double-buffered
     // pipeline (each workgroup hides its own load latency) measured 15-25 % faster
