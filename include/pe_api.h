@@ -394,6 +394,11 @@ int32_t pe_mul_f32(float* a, const float* b, int64_t n, pe_stream_t stream);
  *   bwd   : g = da masked by (a > 0) (relu = 1) or (0 < a < 6) (relu = 2) when a != NULL;
  *           dbeta = sum g; dgamma = sum g*xhat;
  *           dz = gamma*rstd*(g - dbeta/M - xhat*dgamma/M); dmasked (may be NULL) receives g.
+ *           For a layer without a residual the mask can be rebuilt from z instead of read: pass
+ *           a = NULL and act_scale / act_shift = the scale / shift its forward apply used (the
+ *           stored activation is recomputed with the same operations and rounding, so the
+ *           result is bit-identical and one tensor read per pass is saved); both NULL with
+ *           a = NULL means no activation.
  * C must be a multiple of 8, at most 2048.  workspace: pe_bn_workspace_bytes(M, C).
  * Reductions are ordered: results are bit-stable from run to run.
  * ---------------------------------------------------------------------- */
@@ -406,7 +411,8 @@ int32_t pe_bn_apply_bf16(const void* z, int64_t M, int32_t C, const float* scale
                          const float* shift, const void* residual, int32_t relu, void* y,
                          pe_stream_t stream);
 int32_t pe_bn_bwd_bf16(const void* da, const void* a, int32_t relu, const void* z, int64_t M, int32_t C,
-                       const float* gamma, const float* mean, const float* rstd, float* dgamma,
+                       const float* gamma, const float* mean, const float* rstd,
+                       const float* act_scale, const float* act_shift, float* dgamma,
                        float* dbeta, void* dz, void* dmasked, void* workspace,
                        pe_stream_t stream);
 

@@ -200,7 +200,7 @@ SIGNATURES = {
     "pe_bn_bwd_bf16": (
         c_int32,
         [c_void_p, c_void_p, c_int32, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p,
-         c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
+         c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     ),
 }
 

@@ -53,12 +53,29 @@ __device__ __forceinline__ uint4 pack8(const float* f) {
     return o;
 }
 
+// The bf16 activation bn_apply stored for a layer WITHOUT a residual, recomputed from z: the same
+// float operations (multiply, add, clamp) and the same rounding, so masks derived from it equal
+// masks derived from the stored tensor bit for bit and backward need not read that tensor.
+__device__ __forceinline__ void recompute_act8(const float* zf, const float* __restrict__ msc,
+                                               const float* __restrict__ msh, int c0, float act_hi,
+                                               float* af) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        float v = zf[i] * msc[c0 + i] + msh[c0 + i];
+        v = fmaxf(v, 0.0f);
+        if (act_hi == 6.0f) v = fminf(v, 6.0f);
+        af[i] = bf16_bits_to_float(float_to_bf16_bits(v));
+    }
+}
+
 // MODE 0: s1 = sum z, s2 = sum z*z.   MODE 1: g = da * (0 < a < act_hi if a given); s1 = sum g,
 // s2 = sum g*z.  act_hi = +inf for ReLU, 6 for ReLU6.  partial layout: [nblk][2][C].
 template <int MODE>
 __global__ __launch_bounds__(256) void bn_reduce_kernel(const uint16_t* __restrict__ z,
                                                         const uint16_t* __restrict__ da,
                                                         const uint16_t* __restrict__ a,
+                                                        const float* __restrict__ msc,
+                                                        const float* __restrict__ msh,
                                                         float act_hi, long M, int C, BnGeom g,
                                                         float* __restrict__ partial) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -106,9 +123,10 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const uint16_t* __restri
             } else {
                 float gf[8];
                 unpack8(gv[u], gf);
-                if (a) {
+                if (a || msc) {
                     float af[8];
-                    unpack8(av[u], af);
+                    if (a) unpack8(av[u], af);
+                    else recompute_act8(zf, msc, msh, cgi * 8, act_hi, af);
 #pragma unroll
                     for (int i = 0; i < 8; ++i)
                         gf[i] = (af[i] > 0.0f && af[i] < act_hi) ? gf[i] : 0.0f;
@@ -267,15 +285,17 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
     const uint16_t* __restrict__ da, const uint16_t* __restrict__ a, const uint16_t* __restrict__ z,
     long nchunk, int cg, const float* __restrict__ mean, const float* __restrict__ coefA,
     const float* __restrict__ coefB, const float* __restrict__ coefC, float act_hi,
+    const float* __restrict__ msc, const float* __restrict__ msh,
     uint16_t* __restrict__ dz, uint16_t* __restrict__ dmasked) {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nchunk; i += (long)gridDim.x * 256) {
         const int c0 = (int)(i % cg) * 8;
         float g[8], zf[8];
         unpack8(*reinterpret_cast<const uint4*>(da + i * 8), g);
         unpack8(*reinterpret_cast<const uint4*>(z + i * 8), zf);
-        if (a) {
+        if (a || msc) {
             float af[8];
-            unpack8(*reinterpret_cast<const uint4*>(a + i * 8), af);
+            if (a) unpack8(*reinterpret_cast<const uint4*>(a + i * 8), af);
+            else recompute_act8(zf, msc, msh, c0, act_hi, af);
 #pragma unroll
             for (int k = 0; k < 8; ++k) g[k] = (af[k] > 0.0f && af[k] < act_hi) ? g[k] : 0.0f;
         }
@@ -352,7 +372,7 @@ extern "C" int32_t pe_bn_stats_bf16(const void* z, int64_t M, int32_t C, const f
     float* partial = static_cast<float*>(workspace);
     hipStream_t st = as_stream(stream);
     bn_reduce_kernel<0><<<g.nblk, 256, (size_t)g.rl * 2 * C * sizeof(float), st>>>(
-        static_cast<const uint16_t*>(z), nullptr, nullptr, 0.0f, M, C, g, partial);
+        static_cast<const uint16_t*>(z), nullptr, nullptr, nullptr, nullptr, 0.0f, M, C, g, partial);
     rc = check_launch("pe_bn_stats_bf16(reduce)");
     if (rc != PE_OK) return rc;
     const BnFwdOut o{mean, rstd, scale, shift, running_mean, running_var};
@@ -381,7 +401,8 @@ extern "C" int32_t pe_bn_apply_bf16(const void* z, int64_t M, int32_t C, const f
 
 extern "C" int32_t pe_bn_bwd_bf16(const void* da, const void* a, int32_t relu, const void* z,
                                   int64_t M, int32_t C, const float* gamma, const float* mean,
-                                  const float* rstd, float* dgamma, float* dbeta, void* dz,
+                                  const float* rstd, const float* act_scale,
+                                  const float* act_shift, float* dgamma, float* dbeta, void* dz,
                                   void* dmasked, void* workspace, pe_stream_t stream) {
     int32_t rc = bn_check("pe_bn_bwd_bf16", M, C);
     if (rc != PE_OK) return rc;
@@ -392,6 +413,8 @@ extern "C" int32_t pe_bn_bwd_bf16(const void* da, const void* a, int32_t relu, c
                PE_E_INVALID, "pe_bn_bwd_bf16: tensors must be 16-byte aligned");
     PE_REQUIRE(relu == 1 || relu == 2, PE_E_INVALID,
                "pe_bn_bwd_bf16: relu must be 1 (ReLU) or 2 (ReLU6); it only matters when a is given");
+    PE_REQUIRE((act_scale == nullptr) == (act_shift == nullptr) && !(a && act_scale), PE_E_INVALID,
+               "pe_bn_bwd_bf16: give the stored activation a, or act_scale and act_shift, not both");
     const float act_hi = relu == 2 ? 6.0f : INFINITY;
     const BnGeom g = bn_geom(M, C);
     float* partial = static_cast<float*>(workspace);
@@ -401,7 +424,7 @@ extern "C" int32_t pe_bn_bwd_bf16(const void* da, const void* a, int32_t relu, c
     hipStream_t st = as_stream(stream);
     bn_reduce_kernel<1><<<g.nblk, 256, (size_t)g.rl * 2 * C * sizeof(float), st>>>(
         static_cast<const uint16_t*>(z), static_cast<const uint16_t*>(da),
-        static_cast<const uint16_t*>(a), act_hi, M, C, g, partial);
+        static_cast<const uint16_t*>(a), act_scale, act_shift, act_hi, M, C, g, partial);
     rc = check_launch("pe_bn_bwd_bf16(reduce)");
     if (rc != PE_OK) return rc;
     bn_bwd_finalize_kernel<<<(C + kFoldCh - 1) / kFoldCh, 256, 0, st>>>(partial, g.nblk, C,
@@ -413,6 +436,6 @@ extern "C" int32_t pe_bn_bwd_bf16(const void* da, const void* a, int32_t relu, c
     bn_bwd_apply_kernel<<<ew_grid(nchunk), 256, 0, st>>>(
         static_cast<const uint16_t*>(da), static_cast<const uint16_t*>(a),
         static_cast<const uint16_t*>(z), nchunk, C / 8, mean, coefA, coefB, coefC, act_hi,
-        static_cast<uint16_t*>(dz), static_cast<uint16_t*>(dmasked));
+        act_scale, act_shift, static_cast<uint16_t*>(dz), static_cast<uint16_t*>(dmasked));
     return check_launch("pe_bn_bwd_bf16(apply)");
 }

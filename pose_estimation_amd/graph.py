@@ -424,11 +424,15 @@ class TrainGraph:
                     raise RuntimeError(f"layer {L.name}: output received no gradient")
                 buf = self.bn_rows[L.name]
                 masked = residual is not None and act != 0
-                dz, g = pnn.bn_bwd(out.grad, out.t if act else None, z,
+                # without a residual the activation mask is rebuilt from z (scale and shift of the
+                # forward pass are still in the layer's rows): one tensor read less per pass
+                rebuild = act != 0 and residual is None
+                dz, g = pnn.bn_bwd(out.grad, out.t if (act and not rebuild) else None, z,
                                    self.view(self.master, L.name + ".bn.gamma"), buf[0], buf[1],
                                    self._g(L.name + ".bn.gamma"), self._g(L.name + ".bn.beta"),
                                    self._workspace_for(z.numel() // L.cout, L.cout), masked,
-                                   relu=act or 1)
+                                   relu=act or 1, act_scale=buf[2] if rebuild else None,
+                                   act_shift=buf[3] if rebuild else None)
                 if residual is not None:
                     self._acc(residual, g if masked else out.grad)
                 self._weight_grad(L, x.t, dz)

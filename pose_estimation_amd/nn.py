@@ -759,9 +759,12 @@ def bn_apply(z: torch.Tensor, scale, shift, residual=None, relu: int = 1,
 
 
 def bn_bwd(da: torch.Tensor, a: Optional[torch.Tensor], z: torch.Tensor, gamma, mean, rstd,
-           dgamma, dbeta, ws: torch.Tensor, want_masked: bool = False, dz=None, relu: int = 1):
+           dgamma, dbeta, ws: torch.Tensor, want_masked: bool = False, dz=None, relu: int = 1,
+           act_scale=None, act_shift=None):
     """Returns (dz, g) where g = da masked by the activation that produced `a` (relu 1: ReLU,
-    2: ReLU6; no mask when a is None); g is None unless want_masked."""
+    2: ReLU6; no mask when a is None); g is None unless want_masked.  For a layer without a
+    residual, a = None with act_scale / act_shift (what its bn_apply used) rebuilds the mask from
+    z instead of reading the stored activation."""
     _check_act(da, "da")
     C = z.shape[3]
     M = z.numel() // C
@@ -771,7 +774,8 @@ def bn_bwd(da: torch.Tensor, a: Optional[torch.Tensor], z: torch.Tensor, gamma, 
     with on_device(z):
         check(lib().pe_bn_bwd_bf16(da.data_ptr(), _ptr(a), int(relu), z.data_ptr(), M, C,
                                    gamma.data_ptr(),
-                                   mean.data_ptr(), rstd.data_ptr(), dgamma.data_ptr(),
+                                   mean.data_ptr(), rstd.data_ptr(), _ptr(act_scale),
+                                   _ptr(act_shift), dgamma.data_ptr(),
                                    dbeta.data_ptr(), dz.data_ptr(), _ptr(g), ws.data_ptr(),
                                    _stream(z)))
     return dz, g

@@ -167,12 +167,12 @@ class TrainablePoseResNet(PoseResNet):
                 self._done(b.c3)
             res = g3
         da2 = pnn.conv2d_bwd_data(dz3, self.wt[b.c3.name], tuple(s["a2"].shape[1:3]), 1, 1, 0)
-        dz2, _ = self._bn_bwd(b.c2, da2, s["a2"], s["z2"])
+        dz2, _ = self._bn_bwd(b.c2, da2, s["a2"], s["z2"], rebuild=True)
         with self._beside(s["a1"], dz2):
             pnn.conv2d_bwd_weight(s["a1"], dz2, self._g(b.c2.name + ".weight"), 3, b.c2.stride, 1)
             self._done(b.c2)
         da1 = pnn.conv2d_bwd_data(dz2, self.wt[b.c2.name], hw_mid, 3, b.c2.stride, 1)
-        dz1, _ = self._bn_bwd(b.c1, da1, s["a1"], s["z1"])
+        dz1, _ = self._bn_bwd(b.c1, da1, s["a1"], s["z1"], rebuild=True)
         with self._beside(x, dz1):
             pnn.conv2d_bwd_weight(x, dz1, self._g(b.c1.name + ".weight"), 1, 1, 0)
             self._done(b.c1)
@@ -184,7 +184,7 @@ class TrainablePoseResNet(PoseResNet):
         return dict(x=x, z=z, a=self._bn(d, z, rows))
 
     def deconv_backward(self, d, s: dict, da: torch.Tensor) -> torch.Tensor:
-        dz, _ = self._bn_bwd(d, da, s["a"], s["z"])
+        dz, _ = self._bn_bwd(d, da, s["a"], s["z"], rebuild=True)
         with self._beside(s["x"], dz):
             pnn.deconv4x4s2_bwd_weight(s["x"], dz, self._g(d.name + ".weight"))
             self._done(d)
@@ -217,10 +217,15 @@ class TrainablePoseResNet(PoseResNet):
         return hm
 
     # ------------------------------------------------------------------ backward
-    def _bn_bwd(self, c: ConvSpec, da, a, z, want_masked=False):
+    def _bn_bwd(self, c: ConvSpec, da, a, z, want_masked=False, rebuild=False):
+        """rebuild: the layer has a ReLU and no residual, so its mask is rebuilt from z with the
+        scale and shift its forward pass left in the layer's rows, instead of reading `a`."""
         buf = self.bn_rows[c.name]
-        return pnn.bn_bwd(da, a, z, self._gamma(c), buf[0], buf[1], self._g(c.name + ".bn.gamma"),
-                          self._g(c.name + ".bn.beta"), self._workspace(z), want_masked)
+        return pnn.bn_bwd(da, None if rebuild else a, z, self._gamma(c), buf[0], buf[1],
+                          self._g(c.name + ".bn.gamma"), self._g(c.name + ".bn.beta"),
+                          self._workspace(z), want_masked,
+                          act_scale=buf[2] if rebuild else None,
+                          act_shift=buf[3] if rebuild else None)
 
     def _done(self, c: ConvSpec) -> None:
         if self.bucketer is not None:
@@ -262,7 +267,7 @@ class TrainablePoseResNet(PoseResNet):
             dx = self.block_backward(b, s, dx)
         # stem
         da0 = pnn.maxpool3x3s2_bwd(sv["pool_idx"], dx)
-        dz0, _ = self._bn_bwd(stem, da0, sv["a0"], sv["z0"])
+        dz0, _ = self._bn_bwd(stem, da0, sv["a0"], sv["z0"], rebuild=True)
         gw = self._g(stem.name + ".weight")
         with self._beside(sv["xs"], dz0):
             pnn.stem7x7s2_bwd_weight(sv["xs"], dz0, gw)

@@ -258,6 +258,20 @@ def test_batch_norm_relu6_any_channel_count(shape):
     assert torch.allclose(dgamma.cpu(), gd.grad.float(), rtol=2e-3, atol=2e-3 * gd.grad.abs().max().item())
     assert torch.allclose(dbeta.cpu(), bd.grad.float(), rtol=2e-3, atol=2e-3 * bd.grad.abs().max().item())
     assert torch.equal(gm.float().cpu(), (da * mask.float()))
+    # the mask rebuilt from z (no read of the stored activation) gives the same bits, for ReLU6
+    # and for ReLU
+    for relu in (2, 1):
+        a_r = pnn.bn_apply(zg, scale, shift, None, relu=relu)
+        dg1, db1 = torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+        dg2, db2 = torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+        dz1, g1 = pnn.bn_bwd(da.to(BF16).cuda(), a_r, zg, gamma.cuda(), mean, rstd, dg1, db1, ws,
+                             want_masked=True, relu=relu)
+        dz1 = dz1.clone()
+        dz2, g2 = pnn.bn_bwd(da.to(BF16).cuda(), None, zg, gamma.cuda(), mean, rstd, dg2, db2, ws,
+                             want_masked=True, relu=relu, act_scale=scale, act_shift=shift)
+        assert torch.equal(dz1, dz2) and torch.equal(g1, g2)
+        assert torch.equal(dg1, dg2) and torch.equal(db1, db2)
+        assert (g2 == 0).any() and (g2 != 0).any()
 
 
 @pytest.mark.parametrize("cfg", [
