@@ -29,16 +29,19 @@ def bench(shape, iters):
     # several input buffers so a small layer is not served from cache by construction
     nbuf = 3
     xs = [torch.randn((B, H, W, Cin), generator=g).to(torch.bfloat16).to(dev) for _ in range(nbuf)]
-    w = pnn.pack_conv_weight(torch.randn((Cout, Cin, k, k), generator=g) * 0.05).to(dev)
+    wf = torch.randn((Cout, Cin, k, k), generator=g) * 0.05
+    narrow = Cin in (8, 16, 32)
+    w = (pnn.pack_conv_weight_narrow(wf) if narrow else pnn.pack_conv_weight(wf)).to(dev)
+    kw = {"kw": k} if narrow else {}
     Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
     out = torch.empty((B, Ho, Wo, Cout), dtype=torch.bfloat16, device=dev)
     for i in range(3):
-        pnn.conv2d(xs[i % nbuf], w, stride=stride, pad=pad, relu=RELU, out=out)
+        pnn.conv2d(xs[i % nbuf], w, stride=stride, pad=pad, relu=RELU, out=out, **kw)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for i in range(iters):
-        pnn.conv2d(xs[i % nbuf], w, stride=stride, pad=pad, relu=RELU, out=out)
+        pnn.conv2d(xs[i % nbuf], w, stride=stride, pad=pad, relu=RELU, out=out, **kw)
     e1.record()
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / iters
