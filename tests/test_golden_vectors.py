@@ -164,3 +164,128 @@ def test_hip_blocks_match_golden(v):
     assert rel_l2(got, v["deconv_dw_sample"]) <= 2e-2
     assert rel_l2(net.view(net.grads, d.name + ".bn.gamma").cpu(), v["deconv_dgamma"]) <= 2e-2
     assert rel_l2(net.view(net.grads, d.name + ".bn.beta").cpu(), v["deconv_dbeta"]) <= 2e-2
+
+
+# ============================================================ tape-graph networks (graph_vectors.npz)
+import make_graph_vectors as mg  # noqa: E402
+
+GRAPH_GOLD = Path(__file__).resolve().parent / "golden" / "graph_vectors.npz"
+
+
+@pytest.fixture(scope="module")
+def gv():
+    with np.load(GRAPH_GOLD, allow_pickle=False) as z:
+        return {k: z[k] for k in z.files}
+
+
+def test_oracle_graph_blocks_match_golden(gv):
+    """One HRNet-style exchange module and two MobileNetV2 inverted-residual blocks: the torch-CPU
+    oracle still gives the frozen outputs, input gradients and parameter gradients."""
+    spec, state, m, xs, douts = mg.hrnet_case()
+    outs, dxs, rg = to.hrnet_module_train_reference(m, state, xs, douts)
+    assert len(outs) == 3 and len(rg) > 0
+    for i, (o, d) in enumerate(zip(outs, dxs)):
+        assert rel_l2(o, gv[f"hr_out{i}"]) < 1e-5 and rel_l2(d, gv[f"hr_dx{i}"]) < 1e-4
+    for nm in rg:
+        flat = rg[nm].reshape(-1)
+        got = flat[::mg.SAMPLE_STEP] if nm.endswith(".weight") else flat
+        assert rel_l2(got, gv["hr_g_" + nm]) < 1e-4, nm
+        assert flat.norm().item() == pytest.approx(float(gv["hr_n_" + nm]), rel=1e-4)
+    blocks, mstate, cases = mg.mobilenet_case()
+    assert [b.residual for b, _, _ in cases] == [True, False]
+    assert [b.stride for b, _, _ in cases] == [1, 2]
+    for b, x, dout in cases:
+        out, dx, g = to.mobilenet_block_train_reference(b, mstate, x, dout)
+        assert rel_l2(out, gv[f"mb_{b.name}_out"]) < 1e-5
+        assert rel_l2(dx, gv[f"mb_{b.name}_dx"]) < 1e-4
+        for nm in g:
+            assert rel_l2(g[nm].reshape(-1), gv["mb_g_" + nm]) < 1e-4, nm
+
+
+@pytest.mark.gpu
+def test_hip_hrnet_module_matches_golden(gv):
+    """The tape graph's exchange module through libpe_hip.so against the frozen oracle vectors:
+    outputs within one bf16 ulp of the largest value, input gradients 2e-2 relative L2 (the bounds
+    of test_gpu_hrnet_train.py); parameter gradients 3e-2: the widest branch has 96 cells per
+    channel here, where a single activation that rounds to the other side of zero moves that
+    channel's batch-norm sums by a percent."""
+    from pose_estimation_amd import hrnet
+    from pose_estimation_amd.graph import Var
+
+    spec, state, m, xs, douts = mg.hrnet_case()
+    net = hrnet.TrainablePoseHRNet("cuda:0", num_joints=17, **mg.HR_CFG)
+    net.load_state(state)
+    m = net.spec.stages[mg.HR_STAGE][0]
+    net.grads.zero_()
+    net.begin(True)
+    xv = [Var(x.to(torch.bfloat16).cuda(), True) for x in xs]
+    outs = net._module(m, xv)
+    for o, d in zip(outs, douts):
+        o.grad = d.to(torch.bfloat16).cuda()
+    net.backward({})
+    torch.cuda.synchronize()
+    for i, (o, x) in enumerate(zip(outs, xv)):
+        ref = gv[f"hr_out{i}"]
+        assert np.abs(o.t.float().cpu().numpy() - ref).max() <= 8e-3 * np.abs(ref).max() + 1e-6
+        assert rel_l2(x.grad.float().cpu(), gv[f"hr_dx{i}"]) <= 2e-2
+    checked = 0
+    for key in gv:
+        if not key.startswith("hr_g_"):
+            continue
+        nm = key[len("hr_g_"):]
+        got = net.view(net.grads, nm).cpu()
+        assert got.norm().item() == pytest.approx(float(gv["hr_n_" + nm]), rel=2e-2), nm
+        if not nm.endswith(".weight"):
+            assert rel_l2(got.reshape(-1), gv[key]) <= 3e-2, nm
+        checked += 1
+    assert checked >= 20
+
+
+@pytest.mark.gpu
+def test_hip_mobilenet_blocks_match_golden(gv):
+    """Inverted-residual blocks (stride 1 with the residual, stride 2) through libpe_hip.so against
+    the frozen oracle vectors; bounds of test_gpu_mobilenet_train.py."""
+    from pose_estimation_amd import mobilenet as mb
+    from pose_estimation_amd.graph import Var
+
+    blocks, mstate, cases = mg.mobilenet_case()
+    net = mb.TrainablePoseMobileNetV2("cuda:0", num_joints=17, pairs=None, setting=mg.MB_SETTING)
+    net.load_state(mstate)
+    for (b0, x, dout), b in zip(cases, [net.blocks[i] for i in mg.MB_BLOCKS]):
+        assert b.name == b0.name
+        xp = torch.zeros(*x.shape[:3], mb.pad64(b.cin))
+        xp[..., :b.cin] = x
+        dp = torch.zeros(*dout.shape[:3], mb.pad64(b.cout))
+        dp[..., :b.cout] = dout
+        net.grads.zero_()
+        net.begin(True)
+        xv = Var(xp.to(torch.bfloat16).cuda(), True)
+        out = net.block(b, xv)
+        out.grad = dp.to(torch.bfloat16).cuda()
+        net.backward({})
+        torch.cuda.synchronize()
+        ref = gv[f"mb_{b.name}_out"]
+        o = out.t.float().cpu().numpy()
+        assert not o[..., b.cout:].any()
+        assert np.abs(o[..., :b.cout] - ref).max() <= 8e-3 * np.abs(ref).max() + 1e-6
+        dx = xv.grad.float().cpu()
+        assert not dx[..., b.cin:].any()
+        assert rel_l2(dx[..., :b.cin], gv[f"mb_{b.name}_dx"]) <= 2e-2
+        for key in gv:
+            nm = key[len("mb_g_"):]
+            if not key.startswith("mb_g_" + b.name + "."):
+                continue
+            got = net.view(net.grads, nm).cpu()
+            n = gv[key].size
+            if nm.endswith(".weight"):
+                L = net.by_name[nm.rsplit(".", 1)[0]]
+                if L.kind == "dw":                       # [9, Cpad] -> [C, 1, 3, 3]
+                    c = n // 9
+                    got = got[:, :c].t().reshape(-1)
+                else:                                    # [Cout_pad, 1, 1, Cin_pad] -> [Cout, Cin]
+                    co = {"expand": b.mid, "project": b.cout}.get(nm.split(".")[1], None)
+                    co = co or got.shape[0]
+                    got = got[:co, 0, 0, :n // co].reshape(-1)
+            else:
+                got = got[:n]
+            assert rel_l2(got, gv[key]) <= 2e-2, nm
