@@ -636,6 +636,9 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="decode", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-also", action="store_true",
+                    help="default workload only: skip the inference and training legs")
+    ap.add_argument("--also-timeout", type=float, default=240.0)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -659,45 +662,49 @@ def main() -> None:
         else:
             dist.init_process_group("nccl", device_id=device)
 
-    wl = WORKLOADS[args.workload]()
-    wl.setup(device)
-
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize(device)
 
-    for i in range(args.warmup):
-        wl.step(i)
-    barrier()
-    ev0 = torch.cuda.Event(enable_timing=True)
-    ev1 = torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record()
-    for i in range(args.steps):
-        wl.step(i)
-    ev1.record()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    dev_ms = ev0.elapsed_time(ev1)  # same stream as the launches (torch's current stream)
+    def measure(wl, steps, warmup):
+        """W untimed steps, then exactly K steps between barrier + synchronize on both sides;
+        (wall seconds, device milliseconds between HIP events on the launch stream), each the
+        maximum over ranks."""
+        wl.setup(device)
+        for i in range(warmup):
+            wl.step(i)
+        barrier()
+        ev0 = torch.cuda.Event(enable_timing=True)
+        ev1 = torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        ev0.record()
+        for i in range(steps):
+            wl.step(i)
+        ev1.record()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        dev_ms = ev0.elapsed_time(ev1)  # same stream as the launches (torch's current stream)
+        if dist is not None:
+            t = torch.tensor([elapsed, dev_ms], dtype=torch.float64,
+                             device="cpu" if rehearse else device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed, dev_ms = float(t[0]), float(t[1])
+        return elapsed, dev_ms
 
-    if dist is not None:
-        t = torch.tensor([elapsed, dev_ms], dtype=torch.float64,
-                         device="cpu" if rehearse else device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed, dev_ms = float(t[0]), float(t[1])
-
-    if rank == 0:
-        ms_per_step = elapsed * 1e3 / args.steps
-        kern_ms = dev_ms / args.steps
+    def roofline_of(wl, kern_ms):
         if hasattr(wl, "roofline"):
-            roof = wl.roofline(kern_ms)
-        else:
-            achieved = wl.bytes_per_step / (kern_ms * 1e-3) / 1e9
-            roof = {"bound": wl.bound, "kernel": wl.kernel, "achieved": achieved,
-                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                    "bytes_per_launch": wl.bytes_per_step, "launch_ms": kern_ms,
-                    "traffic": None}
+            return wl.roofline(kern_ms)
+        achieved = wl.bytes_per_step / (kern_ms * 1e-3) / 1e9
+        return {"bound": wl.bound, "kernel": wl.kernel, "achieved": achieved,
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "bytes_per_launch": wl.bytes_per_step, "launch_ms": kern_ms,
+                "traffic": None}
+
+    wl = WORKLOADS[args.workload]()
+    elapsed, dev_ms = measure(wl, args.steps, args.warmup)
+    out = None
+    if rank == 0:
         out = {
             "metric": METRIC,
             "value": world * wl.batch * args.steps / elapsed,
@@ -705,7 +712,7 @@ def main() -> None:
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": ms_per_step,
+            "ms_per_step": elapsed * 1e3 / args.steps,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -714,7 +721,7 @@ def main() -> None:
             "config": {"workload": wl.name, "batch_per_gpu": wl.batch, "joints": K_JOINTS,
                        "heatmap": list(getattr(wl, "heatmap", (H, W))),
                        "sharding": getattr(wl, "sharding", "batch, no collective")},
-            "roofline": roof,
+            "roofline": roofline_of(wl, dev_ms / args.steps),
         }
         # HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE,
         # gfx950-corrected); null when this workload has not been profiled.
@@ -725,6 +732,52 @@ def main() -> None:
                 out["roofline"]["traffic"] = rec["traffic_bytes_per_launch"]
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = wl.cpu_baseline()
+
+    # The metric also names network inference and the data-parallel training step.  A default
+    # run measures them after the headline workload, with the same barrier-bracketed loop, and
+    # reports them under "also" in the same JSON line (whole-job images/s over all ranks), so a
+    # 1/2/4/8-GPU sweep of this script shows how the training step's gradient all-reduce scales.
+    # They never change "value".  A failure or a stall in them must not lose the headline
+    # number: errors are recorded, and a watchdog prints the line and ends the process.
+    if args.workload == "decode" and not args.no_also:
+        import threading
+
+        also = {}
+        if out is not None:
+            out["also"] = also
+
+        def give_up():
+            if out is not None:
+                also.setdefault("error", f"secondary workloads exceeded {args.also_timeout} s")
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+
+        dog = threading.Timer(args.also_timeout, give_up)
+        dog.daemon = True
+        dog.start()
+        wl = None
+        torch.cuda.empty_cache()
+        steps2, warm2 = max(1, min(args.steps, 50)), max(1, min(args.warmup, 10))
+        for key in ("infer", "train"):
+            try:
+                w2 = WORKLOADS[key]()
+                e2, d2 = measure(w2, steps2, warm2)
+                also[key] = {"value": world * w2.batch * steps2 / e2, "unit": "images/s",
+                             "ms_per_step": e2 * 1e3 / steps2, "steps": steps2, "warmup": warm2,
+                             "dtype": w2.dtype,
+                             "config": {"workload": w2.name, "batch_per_gpu": w2.batch,
+                                        "sharding": getattr(w2, "sharding",
+                                                            "batch, no collective")},
+                             "roofline": roofline_of(w2, d2 / steps2)}
+            except Exception as exc:  # noqa: BLE001 - recorded in the line, headline kept
+                also[key] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
+                break   # the ranks may no longer be in step: no further collectives
+            finally:
+                w2 = None
+                torch.cuda.empty_cache()
+        dog.cancel()
+
+    if out is not None:
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
