@@ -622,11 +622,67 @@ class MobileNetTrain(Workload):
                           f"gradients, no loss, no optimizer), batch {B}, one run ({dt:.1f} s)"}
 
 
+class MobileNetDetTrain(MobileNetTrain):
+    """MobileNetTrain plus the reference's third label group (`labels['bboxes']`): two stride-2
+    detection levels with box heads over 1500 anchors, labels assigned on the GPU from one
+    person box per image, objectness + box loss beside the two dense losses."""
+    name = "mobilenetv2_pose_det_train_320x320_b64_bf16"
+
+    def setup(self, device):
+        import torch.distributed as dist
+
+        from pose_estimation_amd import detection
+        from pose_estimation_amd import mobilenet as mb
+
+        self.net = mb.TrainablePoseMobileNetV2(device, pairs=mb.COCO_PAIRS, detection=True)
+        self.net.load_state(mb.init_state(self.net.blocks, K_JOINTS, len(mb.COCO_PAIRS), seed=3,
+                                          det_blocks=self.net.det_blocks))
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            self.net.enable_data_parallel(32 << 20)
+        macs = mb.forward_macs(320, 320, K_JOINTS, len(mb.COCO_PAIRS)) + mb.detection_macs()
+        self.flops_per_step = 3 * 2.0 * macs * self.batch
+        rank = dist.get_rank() if dist.is_initialized() else 0
+        self.imgs = torch.from_numpy(synthetic.images_u8(self.batch, 320, 320, seed=1 + rank)).to(device)
+        self.joints = torch.from_numpy(synthetic.joints(self.batch, K_JOINTS, 320, 320,
+                                                        seed=2 + rank)).to(device)
+        self.anchors = torch.from_numpy(detection.make_anchors()).to(device)
+        self.detection = detection
+
+    def step(self, i):
+        # label assignment is part of the step: boxes -> per-anchor targets on the GPU
+        boxes, cls = self.detection.boxes_from_joints(self.joints, 320, 320)
+        classes, weights, regs, _ = self.detection.anchor_assign(self.anchors, boxes, cls)
+        self.net.train_step(self.imgs, self.joints, None, lr=1e-3,
+                            det_labels=(classes, weights, regs))
+
+    def cpu_baseline(self):
+        from oracle import torch_oracle as to
+        from pose_estimation_amd import mobilenet as mb
+        from pose_estimation_amd import nn as pnn
+
+        blocks = mb.mobilenet_v2_specs()
+        det = mb.detection_specs(blocks[-1].cout)
+        state = mb.init_state(blocks, K_JOINTS, len(mb.COCO_PAIRS), seed=3, det_blocks=det)
+        B = 4
+        img = synthetic.images_u8(B, 320, 320, seed=1)
+        dh = np.zeros((B, K_JOINTS, 40, 40), np.float32)
+        dv = np.zeros((B, 4 * len(mb.COCO_PAIRS), 40, 40), np.float32)
+        db = [torch.zeros(B, 15, 20, 20), torch.zeros(B, 15, 10, 10)]
+        t0 = time.perf_counter()
+        to.mobilenet_train_reference(blocks, state, img, pnn.IMAGENET_MEAN, pnn.IMAGENET_STD, dh, dv,
+                                     det_blocks=det, dboxes=db)
+        dt = time.perf_counter() - t0
+        return {"value": B / dt, "unit": "images/s", "cores": torch.get_num_threads(),
+                "kind": "port",
+                "sample": f"torch-CPU autograd oracle (forward + backward from given head "
+                          f"gradients, no loss, no optimizer), batch {B}, one run ({dt:.1f} s)"}
+
+
 WORKLOADS = {"decode": Decode, "render": Render, "mse": Mse, "mse_fused": MseFused, "adam": Adam,
              "vecmap": VecRender, "vecmap_loss": VecLoss, "mobilenet": MobileNetInfer,
              "augment": Augment, "hrnet": HRNetInfer,
              "infer": Infer, "train": Train, "hrnet_train": HRNetTrain,
-             "mobilenet_train": MobileNetTrain}
+             "mobilenet_train": MobileNetTrain, "mobilenet_det_train": MobileNetDetTrain}
 
 
 def main() -> None:

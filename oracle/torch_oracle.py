@@ -547,10 +547,14 @@ def mobilenet_block_train_reference(b, state, x_nhwc, dout_nhwc, bn_eps: float =
 
 
 def mobilenet_train_reference(blocks, state, img_u8, mean, std, dheat, dvec=None,
-                              bn_eps: float = 1e-5, round_bf16: bool = True):
+                              bn_eps: float = 1e-5, round_bf16: bool = True, det_blocks=None,
+                              dboxes=None):
     """Forward with batch statistics and autograd backward of the whole MobileNetV2 pose network,
     the heads seeded with given gradients (float32 [B,K,H,W] / [B,4P,H,W]) instead of a loss.
-    Returns (heat, vec or None, {name: grad in framework layout})."""
+    Returns (heat, vec or None, {name: grad in framework layout}).
+    det_blocks / dboxes: the detection branch (one stride-2 block + one 1x1 box head per level on
+    top of the trunk output) and the seeds of its heads; the box-head maps are then returned as
+    a fourth value."""
     rb = _RoundBoth.apply if round_bf16 else (lambda t: t)
     rw = _RoundFwd.apply if round_bf16 else (lambda t: t)
     P = _grad_params(state)
@@ -568,5 +572,18 @@ def mobilenet_train_reference(blocks, state, img_u8, mean, std, dheat, dvec=None
         vec = F.conv2d(x, rw(P["vec.weight"]), P["vec.bias"])
         outs.append(vec)
         seeds.append(torch.as_tensor(dvec))
+    boxes = []
+    if det_blocks:
+        f = x
+        for i, b in enumerate(det_blocks):
+            f = _mb_block_autograd(b, P, f, round_bf16, bn_eps)
+            m = F.conv2d(f, rw(P[f"box{i + 1}.weight"]), P[f"box{i + 1}.bias"])
+            boxes.append(m)
+            outs.append(m)
+            seeds.append(torch.as_tensor(dboxes[i]))
     torch.autograd.backward(outs, seeds)
-    return heat.detach(), None if vec is None else vec.detach(), {k: p.grad for k, p in P.items()}
+    grads = {k: p.grad for k, p in P.items()}
+    vec_out = None if vec is None else vec.detach()
+    if det_blocks:
+        return heat.detach(), vec_out, grads, [m.detach() for m in boxes]
+    return heat.detach(), vec_out, grads

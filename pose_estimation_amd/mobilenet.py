@@ -68,6 +68,35 @@ def mobilenet_v2_specs(output_stride: int = 8, setting=None, stem_ch: int = 32) 
     return blocks
 
 
+def detection_specs(cin: int, channels: int = 128, expand: int = 2, levels: int = 2) -> List[MBBlock]:
+    """The detection branch's extra feature levels: one stride-2 inverted-residual block per
+    level on top of the stride-8 trunk output, so a 320x320 image gives the 20x20 and 10x10 maps
+    the reference's anchors live on (feat_1 / feat_2, test.ipynb:432-464).  Block shapes are
+    this build's own (the reference's model file is absent)."""
+    out: List[MBBlock] = []
+    for i in range(levels):
+        out.append(MBBlock(f"det{i + 1}", cin, channels, expand, 2, 1, False))
+        cin = channels
+    return out
+
+
+BOX_FIELDS = 5   # per anchor: objectness logit + 4 box regression values
+
+
+def detection_macs(H: int = 320, W: int = 320, cin: int = 320, output_stride: int = 8,
+                   anchors_per_cell: int = 3) -> int:
+    """Multiply-accumulates of the detection branch's forward at the true channel counts."""
+    h, w = H // output_stride, W // output_stride
+    macs = 0
+    for b in detection_specs(cin):
+        if b.expand != 1:
+            macs += h * w * b.cin * b.mid
+        h, w = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+        macs += h * w * 9 * b.mid + h * w * b.mid * b.cout
+        macs += h * w * b.cout * anchors_per_cell * BOX_FIELDS
+    return macs
+
+
 def forward_macs(H: int = 320, W: int = 320, num_joints: int = 17, num_pairs: int = 0,
                  output_stride: int = 8, setting=None) -> int:
     """Multiply-accumulates of one forward at the true (unpadded) channel counts."""
@@ -84,7 +113,8 @@ def forward_macs(H: int = 320, W: int = 320, num_joints: int = 17, num_pairs: in
 
 
 def init_state(blocks: List[MBBlock], num_joints: int = 17, num_pairs: int = 0,
-               seed: int = 3, stem_ch: int = 32) -> Dict[str, torch.Tensor]:
+               seed: int = 3, stem_ch: int = 32, det_blocks: Optional[List[MBBlock]] = None,
+               anchors_per_cell: int = 3) -> Dict[str, torch.Tensor]:
     """Random-init state dict in framework layouts (CPU float32): He-normal convs (fan-out),
     BN gamma 1 / beta 0 / running (0, 1), heads N(0, 0.01) with zero bias."""
     g = torch.Generator().manual_seed(seed)
@@ -110,6 +140,14 @@ def init_state(blocks: List[MBBlock], num_joints: int = 17, num_pairs: int = 0,
     if num_pairs:
         st["vec.weight"] = torch.randn((4 * num_pairs, cf, 1, 1), generator=g) * 0.01
         st["vec.bias"] = torch.zeros(4 * num_pairs)
+    for i, b in enumerate(det_blocks or []):
+        if b.expand != 1:
+            conv(b.name + ".expand", b.mid, b.cin, 1)
+        conv(b.name + ".dw", b.mid, b.mid, 3, groups=b.mid)
+        conv(b.name + ".project", b.cout, b.mid, 1)
+        n = anchors_per_cell * BOX_FIELDS
+        st[f"box{i + 1}.weight"] = torch.randn((n, b.cout, 1, 1), generator=g) * 0.01
+        st[f"box{i + 1}.bias"] = torch.zeros(n)
     return st
 
 
@@ -206,19 +244,55 @@ COCO_PAIRS = [(15, 13), (13, 11), (16, 14), (14, 12), (11, 12), (5, 11), (6, 12)
               (6, 8), (7, 9), (8, 10), (1, 2), (0, 1), (0, 2), (1, 3), (2, 4), (3, 5), (4, 6)]
 
 
-def _graph_layers(blocks: List[MBBlock], num_joints: int, num_pairs: int, stem_ch: int = 32):
+def _block_layers(b: MBBlock) -> List[Layer]:
+    layers = []
+    if b.expand != 1:
+        layers.append(Layer(b.name + ".expand", "conv", pad64(b.cin), pad64(b.mid), 1, 1, 2))
+    layers.append(Layer(b.name + ".dw", "dw", pad64(b.mid), pad64(b.mid), 3, b.stride, 2,
+                        b.dilation))
+    layers.append(Layer(b.name + ".project", "conv", pad64(b.mid), pad64(b.cout), 1, 1, 0))
+    return layers
+
+
+def _graph_layers(blocks: List[MBBlock], num_joints: int, num_pairs: int, stem_ch: int = 32,
+                  det_blocks: Optional[List[MBBlock]] = None, anchors_per_cell: int = 3):
     layers = [Layer("stem", "stem3", 3, pad64(stem_ch), 3, 2, 2)]
     for b in blocks:
-        if b.expand != 1:
-            layers.append(Layer(b.name + ".expand", "conv", pad64(b.cin), pad64(b.mid), 1, 1, 2))
-        layers.append(Layer(b.name + ".dw", "dw", pad64(b.mid), pad64(b.mid), 3, b.stride, 2,
-                            b.dilation))
-        layers.append(Layer(b.name + ".project", "conv", pad64(b.mid), pad64(b.cout), 1, 1, 0))
+        layers.extend(_block_layers(b))
     cf = pad64(blocks[-1].cout)
     layers.append(Layer("heat", "head", cf, num_joints))
     if num_pairs:
         layers.append(Layer("vec", "head", cf, 4 * num_pairs))
+    for i, b in enumerate(det_blocks or []):     # forward execution order: level by level
+        layers.extend(_block_layers(b))
+        layers.append(Layer(f"box{i + 1}", "head", pad64(b.cout), anchors_per_cell * BOX_FIELDS))
     return layers
+
+
+def box_outputs(maps: List[torch.Tensor], anchors_per_cell: int = 3):
+    """Box-head maps, float32 [B, A*5, h, w] per level (channel = anchor * 5 + field) ->
+    (logit [B,N], reg [B,N,4]) with anchors ordered level, row, column, anchor: the order of the
+    reference's `classes` / `regs` labels (test.ipynb:423-464, 504-507)."""
+    rows = []
+    for m in maps:
+        B, _, h, w = m.shape
+        rows.append(m.view(B, anchors_per_cell, BOX_FIELDS, h, w).permute(0, 3, 4, 1, 2)
+                    .reshape(B, h * w * anchors_per_cell, BOX_FIELDS))
+    flat = torch.cat(rows, dim=1)
+    return flat[..., 0].contiguous(), flat[..., 1:].contiguous()
+
+
+def box_grads(g_logit: torch.Tensor, g_reg: torch.Tensor, shapes, anchors_per_cell: int = 3):
+    """Inverse of box_outputs for gradients: -> one float32 [B, A*5, h, w] map per level."""
+    flat = torch.cat([g_logit.unsqueeze(-1), g_reg], dim=-1)
+    out, at = [], 0
+    for (h, w) in shapes:
+        n = h * w * anchors_per_cell
+        part = flat[:, at:at + n].reshape(-1, h, w, anchors_per_cell, BOX_FIELDS)
+        out.append(part.permute(0, 3, 4, 1, 2).reshape(-1, anchors_per_cell * BOX_FIELDS, h, w)
+                   .contiguous())
+        at += n
+    return out
 
 
 def pad_state(layers, st: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
@@ -255,12 +329,21 @@ class TrainablePoseMobileNetV2(TrainGraph):
     stride-8 maps, 3x3 supports (test.ipynb:606-653, 919)."""
 
     def __init__(self, device, num_joints: int = 17, pairs=None, output_stride: int = 8,
-                 setting=None, bn_momentum: float = 0.1, sigma: float = 1.0, radius: int = 1):
+                 setting=None, bn_momentum: float = 0.1, sigma: float = 1.0, radius: int = 1,
+                 detection: bool = False, anchors_per_cell: int = 3, box_loss_weight: float = 1.0):
+        """detection: adds the reference's third output (`labels['bboxes']`, test.ipynb:432):
+        two stride-2 feature levels on top of the trunk, each with a 1x1 box head that predicts
+        an objectness logit and four regression values per anchor."""
         self.blocks = mobilenet_v2_specs(output_stride, setting)
         self.pairs = list(pairs) if pairs else []
         self.num_joints = num_joints
         self.num_pairs = len(self.pairs)
-        super().__init__(device, _graph_layers(self.blocks, num_joints, self.num_pairs), bn_momentum)
+        self.det_blocks = detection_specs(self.blocks[-1].cout) if detection else []
+        self.anchors_per_cell = anchors_per_cell
+        self.box_loss_weight = box_loss_weight
+        super().__init__(device, _graph_layers(self.blocks, num_joints, self.num_pairs,
+                                               det_blocks=self.det_blocks,
+                                               anchors_per_cell=anchors_per_cell), bn_momentum)
         self.output_stride = output_stride
         self.sigma = sigma
         self.radius = radius
@@ -278,30 +361,46 @@ class TrainablePoseMobileNetV2(TrainGraph):
         return self.unit(L[b.name + ".project"], h, residual=x if b.residual else None)
 
     def forward(self, x_s2d: torch.Tensor, training: bool):
+        """-> heat, or (heat, vec) with a vector-map head; with the detection branch a third /
+        second entry follows: the list of box-head maps, one float32 [B, A*5, h, w] per level."""
         self.begin(training)
         L = self.by_name
         x = self.unit(L["stem"], Var(x_s2d, False))
         for b in self.blocks:
             x = self.block(b, x)
-        heat = self.head(L["heat"], x)
-        return (heat, self.head(L["vec"], x)) if self.num_pairs else heat
+        outs = [self.head(L["heat"], x)]
+        if self.num_pairs:
+            outs.append(self.head(L["vec"], x))
+        if self.det_blocks:
+            f, maps = x, []
+            for i, b in enumerate(self.det_blocks):
+                f = self.block(b, f)
+                maps.append(self.head(L[f"box{i + 1}"], f))
+            outs.append(maps)
+        return outs[0] if len(outs) == 1 else tuple(outs)
 
     def forward_train(self, images_u8: Optional[torch.Tensor],
                       x_s2d: Optional[torch.Tensor] = None):
         return self.forward(x_s2d if x_s2d is not None else pnn.preprocess_u8(images_u8), True)
 
     def predict(self, images_u8: torch.Tensor):
-        """uint8 [B,H,W,3] -> heat maps (and vector maps), running BN statistics (call fold_bn()
+        """uint8 [B,H,W,3] -> heat maps (and vector maps, and with the detection branch
+        (logit [B,N], reg [B,N,4]) over all anchors), running BN statistics (call fold_bn()
         after training steps)."""
-        return self.forward(pnn.preprocess_u8(images_u8), False)
+        out = self.forward(pnn.preprocess_u8(images_u8), False)
+        if not self.det_blocks:
+            return out
+        return tuple(out[:-1]) + (box_outputs(out[-1], self.anchors_per_cell),)
 
-    def _pass_u8(self, images_u8, joints, mask):
-        return self._pass(pnn.preprocess_u8(images_u8), joints, mask)
+    def _pass_u8(self, images_u8, joints, mask, det_labels=None):
+        return self._pass(pnn.preprocess_u8(images_u8), joints, mask, det_labels)
 
-    def _pass(self, x_s2d, joints, mask):
-        """Forward with batch statistics, both losses, backward: fills the gradient arena."""
+    def _pass(self, x_s2d, joints, mask, det_labels=None):
+        """Forward with batch statistics, the losses of every head, backward: fills the gradient
+        arena.  det_labels: (classes [B,N], weights [B,N], regs [B,N,4]) per-anchor targets as
+        detection.anchor_assign makes them; the detection branch needs them."""
         out = self.forward(x_s2d, True)
-        heat = out[0] if self.num_pairs else out
+        heat = out[0] if isinstance(out, tuple) else out
         s = float(self.output_stride)
         loss, per_joint, grad, _ = ops.mse_fwd_bwd(heat, joints=joints, mask=mask, stride=s,
                                                   sigma=self.sigma, radius=self.radius)
@@ -311,20 +410,41 @@ class TrainablePoseMobileNetV2(TrainGraph):
                                                       mask)
             grads["vec"] = vgrad
             loss = loss + vloss
+        if self.det_blocks:
+            if det_labels is None:
+                raise ValueError("this network has a detection branch: pass det_labels")
+            from . import detection
+
+            maps = out[-1]
+            logit, reg = box_outputs(maps, self.anchors_per_cell)
+            classes, weights, regs = det_labels
+            loss4, g_logit, g_reg = detection.box_loss_fwd_bwd(logit, reg, classes, weights, regs)
+            if self.box_loss_weight != 1.0:
+                g_logit, g_reg = g_logit * self.box_loss_weight, g_reg * self.box_loss_weight
+            gm = box_grads(g_logit, g_reg, [tuple(m.shape[2:]) for m in maps],
+                           self.anchors_per_cell)
+            for i, g in enumerate(gm):
+                grads[f"box{i + 1}"] = g
+            loss = loss + loss4[0:1] * self.box_loss_weight
+            self.last_box_loss = loss4
         self.backward(grads)
         return loss, per_joint
 
     def train_step(self, images_u8, joints: torch.Tensor, mask: Optional[torch.Tensor] = None,
                    lr: float = 1e-3, optimizer: str = "adam", beta1: float = 0.9,
                    beta2: float = 0.999, eps: float = 1e-8, momentum: float = 0.9,
-                   x_s2d: Optional[torch.Tensor] = None, hip_graph: bool = False):
-        """One optimisation step on heat-map loss + vector-map loss; returns
+                   x_s2d: Optional[torch.Tensor] = None, hip_graph: bool = False,
+                   det_labels=None):
+        """One optimisation step on heat-map loss + vector-map loss (+ objectness and box loss
+        with the detection branch, which needs det_labels = (classes, weights, regs)); returns
         (loss [1] device tensor, per_joint [K]).  hip_graph: replay the forward/loss/backward
         pass as one captured HIP graph (see TrainGraph.replay)."""
         fn, x = (self._pass, x_s2d) if x_s2d is not None else (self._pass_u8, images_u8)
         if hip_graph:
+            if self.det_blocks:
+                raise ValueError("HIP-graph replay is not wired for the detection branch")
             loss, per_joint = self.replay(fn, x, joints, mask)
         else:
-            loss, per_joint = fn(x, joints, mask)
+            loss, per_joint = fn(x, joints, mask, det_labels)
         self.optimizer_step(lr, optimizer, beta1, beta2, eps, momentum)
         return loss, per_joint

@@ -61,9 +61,12 @@ class Trainer:
             self.net = mb.TrainablePoseMobileNetV2(
                 self.device, num_joints=m.num_joints,
                 pairs=[tuple(p) for p in pairs] if pairs else None, output_stride=stride,
-                bn_momentum=m.bn_momentum, sigma=m.sigma, radius=int(m.get("radius", 1)))
+                bn_momentum=m.bn_momentum, sigma=m.sigma, radius=int(m.get("radius", 1)),
+                detection=bool(m.get("detection", False)),
+                box_loss_weight=float(m.get("box_loss_weight", 1.0)))
             self.net.load_state(state if state is not None else mb.init_state(
-                self.net.blocks, m.num_joints, self.net.num_pairs, seed))
+                self.net.blocks, m.num_joints, self.net.num_pairs, seed,
+                det_blocks=self.net.det_blocks))
         else:
             raise NotImplementedError(f"backbone {m.backbone!r} is not built yet")
         import torch.distributed as dist
@@ -77,6 +80,28 @@ class Trainer:
         if self.net is None:
             self.build_model()
         return self.net
+
+    # ------------------------------------------------------------------ detection labels
+    def _anchors(self, H: int, W: int) -> torch.Tensor:
+        """Anchors of the two detection levels (strides 16 and 32: 20x20 and 10x10 cells, three
+        per cell, at the reference's 320x320; test.ipynb:423-464)."""
+        from . import detection
+
+        key = (H, W)
+        if getattr(self, "_anchor_key", None) != key:
+            levels = ((H // 16, W // 16), (H // 32, W // 32))
+            self._anchor_cache = torch.from_numpy(detection.make_anchors(levels)).to(self.device)
+            self._anchor_key = key
+        return self._anchor_cache
+
+    def _bbox_labels(self, joints: torch.Tensor, H: int, W: int) -> dict:
+        """`labels['bboxes']` in the reference's keys (`classes`, `weights`, `regs`,
+        test.ipynb:504-507, 571-572), made on the GPU from one person box per image."""
+        from . import detection
+
+        boxes, cls = detection.boxes_from_joints(joints, H, W)
+        classes, weights, regs, _ = detection.anchor_assign(self._anchors(H, W), boxes, cls)
+        return {"classes": classes, "weights": weights, "regs": regs, "boxes": boxes}
 
     # ------------------------------------------------------------------ data (synthetic)
     def get_features_labels_data(self, num_batches: Optional[int] = None
@@ -105,6 +130,8 @@ class Trainer:
             if pairs:   # the reference's second dense label (test.ipynb:925-944)
                 labels["vecmaps"] = ops.render_vecmaps(joints, [tuple(p) for p in pairs], H // s,
                                                        W // s, float(s), layout="NHWC")
+            if self.model_cfg.get("detection"):   # the third label group (test.ipynb:432)
+                labels["bboxes"] = self._bbox_labels(joints, H, W)
             yield ({"images": img}, labels)
             i += 1
 
@@ -113,8 +140,10 @@ class Trainer:
         """train_step(features_dict, labels_dict) or train_step(images_u8, joints[, mask]).
         Returns the loss as a Python float is NOT done here (no sync): a [1] device tensor."""
         net = self._need_model()
+        bb = None
         if isinstance(features, dict):
             images, joints, mask = features["images"], labels["joints"], labels.get("masks")
+            bb = labels.get("bboxes")
         else:
             images, joints = features, labels
         t = self.train_cfg
@@ -142,6 +171,12 @@ class Trainer:
             perm = augment.COCO_FLIP_PERM if joints.shape[1] == 17 else None
             joints = augment.transform_joints(joints, prm_t, W, perm)
             images = None
+            bb = None     # boxes follow the transformed joints
+        kw = {}
+        if getattr(net, "det_blocks", None):
+            if bb is None:
+                bb = self._bbox_labels(joints, H, W)
+            kw["det_labels"] = (bb["classes"], bb["weights"], bb["regs"])
         lr = learning_rate_at(t, self.global_step)
         opt = t.optimizer
         params = opt.get("params", {})
@@ -150,10 +185,11 @@ class Trainer:
             loss, _ = net.train_step(images, joints, mask, lr=lr, optimizer="adam",
                                      beta1=float(params.get("beta1", 0.9)),
                                      beta2=float(params.get("beta2", 0.999)),
-                                     eps=float(params.get("epsilon", 1e-8)), x_s2d=x_s2d)
+                                     eps=float(params.get("epsilon", 1e-8)), x_s2d=x_s2d, **kw)
         elif name in ("sgd", "momentum"):
             loss, _ = net.train_step(images, joints, mask, lr=lr, optimizer="sgd",
-                                     momentum=float(params.get("momentum", 0.9)), x_s2d=x_s2d)
+                                     momentum=float(params.get("momentum", 0.9)), x_s2d=x_s2d,
+                                     **kw)
         else:
             raise ValueError(f"unknown optimizer {name!r}")
         self.global_step += 1

@@ -203,3 +203,118 @@ def test_trainer_with_the_mobilenet_backbone(tmp_path):
     assert torch.equal(h2, heat) and torch.equal(v2, vec)
     # one more step on both: identical trajectories after the round trip
     assert tr.train_step(feats, labels).item() == tr2.train_step(feats, labels).item()
+
+
+def make_det_net(seed, B, H, W):
+    net = mb.TrainablePoseMobileNetV2("cuda:0", num_joints=17, pairs=PAIRS, setting=SMALL,
+                                      detection=True)
+    state = mb.init_state(net.blocks, 17, len(PAIRS), seed=seed, det_blocks=net.det_blocks)
+    randomize_bn(state, seed=seed + 1)
+    for k in ("heat.weight", "vec.weight", "box1.weight", "box2.weight"):
+        state[k] = state[k] * 30.0
+    net.load_state(state)
+    img = synthetic.images_u8(B, H, W, seed=1)
+    joints = torch.from_numpy(synthetic.joints(B, 17, H, W, seed=2)).cuda()
+    return net, state, img, joints
+
+
+def test_detection_branch_against_autograd():
+    """The reference's third output (`labels['bboxes']`, test.ipynb:432): two stride-2 feature
+    levels on the trunk output, each with a box head.  All four heads seeded at once, so the
+    trunk output collects gradients from three consumers.  Same bounds as the whole-network test."""
+    B, H, W = 8, 128, 128
+    net, state, img, joints = make_det_net(31, B, H, W)
+    heat, vec, maps = net.forward_train(torch.from_numpy(img).cuda())
+    assert [tuple(m.shape) for m in maps] == [(B, 15, 8, 8), (B, 15, 4, 4)]
+    _, _, gh, _ = ops.mse_fwd_bwd(heat, joints=joints, stride=8.0, sigma=1.0, radius=1)
+    _, _, gv = ops.vecmap_loss_fwd_bwd(vec, joints, PAIRS, 8.0, 1)
+    gh, gv = gh * 1e3, gv * 1e3
+    g = torch.Generator().manual_seed(9)
+    dboxes = [torch.randn(tuple(m.shape), generator=g) * 1e-2 for m in maps]
+    net.backward({"heat": gh, "vec": gv, "box1": dboxes[0].cuda(), "box2": dboxes[1].cuda()})
+    torch.cuda.synchronize()
+    args = (net.blocks, state, img, pnn.IMAGENET_MEAN, pnn.IMAGENET_STD, gh.cpu(), gv.cpu())
+    kw = dict(det_blocks=net.det_blocks, dboxes=dboxes)
+    rheat, rvec, rg, rmaps = to.mobilenet_train_reference(*args, **kw)
+    fheat, fvec, fg, fmaps = to.mobilenet_train_reference(*args, round_bf16=False, **kw)
+    for got, ref, f32, nm in [(heat, rheat, fheat, "heat"), (vec, rvec, fvec, "vec"),
+                              (maps[0], rmaps[0], fmaps[0], "box1"),
+                              (maps[1], rmaps[1], fmaps[1], "box2")]:
+        e, s = rel_l2(got.cpu(), ref), rel_l2(f32, ref)
+        print(f"{nm}: {e:.3e} (spread {s:.3e})")
+        assert e <= max(2e-2, 3 * s), nm
+    assert any(k.startswith("det2.") for k in rg) and "box2.weight" in rg
+    check_grads(net, rg, 3e-2, fg)
+
+
+def test_detection_training_steps():
+    """End to end with labels made on the GPU: person boxes -> anchor targets -> objectness + box
+    loss beside the heat-map and vector-map losses.  The box loss falls and the run repeats bit
+    for bit."""
+    from pose_estimation_amd import detection
+
+    B, H, W = 8, 128, 128
+    runs = []
+    for rep in range(2):
+        net, state, img, joints = make_det_net(41, B, H, W)
+        anchors = torch.from_numpy(detection.make_anchors(((8, 8), (4, 4)))).cuda()
+        assert anchors.shape[0] == 8 * 8 * 3 + 4 * 4 * 3
+        boxes = torch.tensor([[[0.2, 0.25, 0.8, 0.7]]], device="cuda").repeat(B, 1, 1)
+        boxes = boxes + 0.01 * torch.arange(B, device="cuda").view(B, 1, 1)
+        cls = torch.ones((B, 1), dtype=torch.int32, device="cuda")
+        classes, weights, regs, _ = detection.anchor_assign(anchors, boxes.contiguous(), cls)
+        it = torch.from_numpy(img).cuda()
+        hist = []
+        for _ in range(10):
+            loss, _ = net.train_step(it, joints, lr=2e-3, det_labels=(classes, weights, regs))
+            hist.append((loss.item(), net.last_box_loss[0].item()))
+        runs.append(hist)
+        net.fold_bn()
+        heat, vec, (logit, reg) = net.predict(it)
+        assert tuple(logit.shape) == (B, anchors.shape[0]) and tuple(reg.shape) == (B, anchors.shape[0], 4)
+        assert torch.isfinite(logit).all() and torch.isfinite(reg).all()
+    assert runs[0] == runs[1]
+    box = [h[1] for h in runs[0]]
+    print("box loss:", " ".join(f"{v:.4f}" for v in box))
+    assert box[-1] < box[0]
+    with pytest.raises(ValueError):
+        net.train_step(it, joints)          # detection branch without its labels
+
+
+def test_trainer_with_the_reference_label_set():
+    """All three label groups of the reference's batches (heatmaps, vecmaps, bboxes:
+    test.ipynb:432, 623, 662) at its resolution: 320x320 -> 40x40 maps and 1500 anchors."""
+    from pose_estimation_amd import Trainer, detection
+
+    cfg = {"model_config": {"backbone": "mobilenet_v2", "heatmap_stride": 8, "sigma": 1.0,
+                            "radius": 1, "pairs": [list(p) for p in PAIRS], "detection": True},
+           "train_config": {"batch_size": 4, "preprocess": {"image_resize": [320, 320]}}}
+    tr = Trainer(cfg, device="cuda:0")
+    tr.build_model(seed=5)
+    feats, labels = next(iter(tr.get_features_labels_data(num_batches=1)))
+    bb = labels["bboxes"]
+    assert tuple(bb["classes"].shape) == (4, 1500) and tuple(bb["regs"].shape) == (4, 1500, 4)
+    assert bb["classes"].sum(dim=1).tolist() == [1.0] * 4      # one positive anchor per person
+    # the boxes are the extent of the labelled joints (+ 5 % of the image), restated in NumPy
+    j = labels["joints"].cpu().numpy()
+    for b in range(4):
+        vis = j[b, :, 2] > 0
+        want = np.array([j[b, vis, 1].min() / 320 - 0.05, j[b, vis, 0].min() / 320 - 0.05,
+                         j[b, vis, 1].max() / 320 + 0.05, j[b, vis, 0].max() / 320 + 0.05],
+                        np.float32).clip(0, 1)
+        assert np.allclose(bb["boxes"][b, 0].cpu().numpy(), want, atol=1e-6)
+    # and the positive anchor's regression row is that box (test.ipynb:571-572)
+    pos = bb["classes"][0].argmax().item()
+    assert torch.allclose(bb["regs"][0, pos], bb["boxes"][0, 0])
+    losses = [tr.train_step(feats, labels).item() for _ in range(4)]
+    assert np.isfinite(losses).all() and losses[-1] < losses[0]
+    heat, vec, (logit, reg) = tr.predict(feats["images"])
+    assert tuple(heat.shape) == (4, 17, 40, 40) and tuple(logit.shape) == (4, 1500)
+    # frames of another size with augmentation: boxes are rebuilt from the transformed joints
+    cfg["train_config"]["augmentation"] = {"flip_left_right": True, "scale_range": [0.8, 1.2]}
+    tr2 = Trainer(cfg, device="cuda:0")
+    tr2.build_model(seed=5)
+    big = torch.from_numpy(synthetic.images_u8(4, 480, 640, seed=3)).cuda()
+    jb = torch.from_numpy(synthetic.joints(4, 17, 480, 640, seed=4)).cuda()
+    assert np.isfinite(tr2.train_step(big, jb).item())
+    assert detection.boxes_from_joints(torch.zeros(2, 17, 3).cuda(), 320, 320)[1].tolist() == [[0], [0]]

@@ -82,3 +82,59 @@ def test_mobilenet_channel_padding():
     assert torch.equal(ps["block1.dw.weight"][:96], st["block1.dw.weight"])
     with pytest.raises(KeyError):
         mb.pad_state(layers, {})
+
+
+def test_box_head_layout_follows_the_reference_anchor_order():
+    """Anchors are flattened level by level as [rows, cols, 3] (1500 = 20*20*3 + 10*10*3,
+    test.ipynb:423-464); the box heads' NCHW maps are re-ordered to that list and gradients
+    take the inverse route."""
+    from pose_estimation_amd import mobilenet as mb
+
+    g = torch.Generator().manual_seed(0)
+    maps = [torch.randn((2, 15, 20, 20), generator=g), torch.randn((2, 15, 10, 10), generator=g)]
+    logit, reg = mb.box_outputs(maps)
+    assert tuple(logit.shape) == (2, 1500) and tuple(reg.shape) == (2, 1500, 4)
+    r, c, a = 7, 13, 2
+    n = (r * 20 + c) * 3 + a
+    assert logit[1, n] == maps[0][1, a * 5, r, c]
+    assert torch.equal(reg[1, n], maps[0][1, a * 5 + 1:a * 5 + 5, r, c])
+    n2 = 1200 + (4 * 10 + 9) * 3 + 1
+    assert logit[0, n2] == maps[1][0, 5, 4, 9]
+    back = mb.box_grads(logit, reg, [(20, 20), (10, 10)])
+    assert all(torch.equal(b, m) for b, m in zip(back, maps))
+    layers = mb._graph_layers(mb.mobilenet_v2_specs(), 17, 2,
+                              det_blocks=mb.detection_specs(320))
+    names = [L.name for L in layers]
+    assert names[-8:] == ["det1.expand", "det1.dw", "det1.project", "box1",
+                          "det2.expand", "det2.dw", "det2.project", "box2"]
+    assert layers[-1].cout == 15 and layers[-1].kind == "head"
+
+
+def test_oracle_detection_branch_autograd_is_consistent():
+    """The CPU restatement of the detection branch: every parameter of the branch receives a
+    gradient, and the trunk's gradients change when the box heads are seeded."""
+    import numpy as np
+    from oracle import torch_oracle as to
+    from pose_estimation_amd import mobilenet as mb
+    from pose_estimation_amd import nn as pnn
+    from pose_estimation_amd import synthetic
+
+    setting = [(1, 16, 1, 1), (6, 24, 1, 2)]
+    blocks = mb.mobilenet_v2_specs(8, setting)
+    det = mb.detection_specs(blocks[-1].cout, channels=32)
+    state = mb.init_state(blocks, 3, 0, seed=1, det_blocks=det)
+    img = synthetic.images_u8(2, 32, 32, seed=1)
+    dheat = np.zeros((2, 3, 8, 8), np.float32)
+    g = torch.Generator().manual_seed(2)
+    dboxes = [torch.randn((2, 15, 4, 4), generator=g), torch.randn((2, 15, 2, 2), generator=g)]
+    heat, vec, grads, maps = to.mobilenet_train_reference(
+        blocks, state, img, pnn.IMAGENET_MEAN, pnn.IMAGENET_STD, dheat, det_blocks=det,
+        dboxes=dboxes)
+    assert vec is None and [tuple(m.shape) for m in maps] == [(2, 15, 4, 4), (2, 15, 2, 2)]
+    for k, v in grads.items():
+        if k.startswith(("det", "box")):
+            assert v is not None and torch.isfinite(v).all() and v.abs().sum() > 0, k
+    assert grads["stem.weight"].abs().sum() > 0      # reached through the detection branch only
+    h2, _, g2 = to.mobilenet_train_reference(blocks, state, img, pnn.IMAGENET_MEAN,
+                                             pnn.IMAGENET_STD, dheat)
+    assert torch.equal(h2, heat) and g2["stem.weight"].abs().sum() == 0
