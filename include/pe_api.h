@@ -416,6 +416,38 @@ int32_t pe_bn_bwd_bf16(const void* da, const void* a, int32_t relu, const void* 
                        float* dbeta, void* dz, void* dmasked, void* workspace,
                        pe_stream_t stream);
 
+/* Backward-data fused with the first half of the batch-norm backward of the layer BELOW: the
+ * result is the gradient da of an activation a = act(z * act_scale + act_shift) (relu 1: ReLU,
+ * 2: ReLU6; z [B,H,W,Cin] bf16 is that layer's pre-norm conv output, act_scale / act_shift the
+ * float32 [Cin] rows its forward normalise pass used).  Instead of da the call stores
+ * g = (0 < a < act_hi) ? da : 0, with a rebuilt from z by the same operations and rounding as
+ * pe_bn_apply_bf16, and every GEMM tile writes one partial row {sum g, sum g*z}[Cin] into
+ * bn_workspace (pe_bn_workspace_bytes(B*H*W, Cin); *rows_out = number of rows, host memory).
+ * pe_bn_bwd_from_partials_bf16 then folds the rows in a fixed order and produces dz, dgamma and
+ * dbeta: together they do what pe_conv2d_bwd_data_bf16 + pe_bn_bwd_bf16(act_scale, act_shift)
+ * do, with one read of da and z and one launch less.  g equals the masked da bit for bit; the
+ * sums differ from pe_bn_bwd_bf16's in summation order only.  No residual; Cin % 8 == 0; a
+ * stride-2 conv needs every input parity to have a tap (3x3 yes, 1x1 no).
+ * Replaces: the gradient graph TensorFlow derived for model/base_model.py, nets/mobilenet_v2.py
+ * (PoseEstimation.pyproj:30-32, absent). */
+int32_t pe_conv2d_bwd_data_bnmask_bf16(const pe_conv_desc* d, const void* dy, const void* w_t,
+                                       const void* z, const float* act_scale,
+                                       const float* act_shift, int32_t relu, void* g,
+                                       void* bn_workspace, size_t workspace_bytes,
+                                       int32_t* rows_out, pe_stream_t stream);
+int32_t pe_deconv4x4s2_bwd_data_bnmask_bf16(int32_t B, int32_t H, int32_t W, int32_t Cin,
+                                            int32_t Cout, const void* dy, const void* w_t,
+                                            const void* z, const float* act_scale,
+                                            const float* act_shift, int32_t relu, void* g,
+                                            void* bn_workspace, size_t workspace_bytes,
+                                            int32_t* rows_out, pe_stream_t stream);
+/* g: the masked gradient and workspace: the partial rows one of the two calls above left
+ * (the three coefficient rows of the element-wise pass go behind them). */
+int32_t pe_bn_bwd_from_partials_bf16(const void* g, const void* z, int32_t rows, int64_t M,
+                                     int32_t C, const float* gamma, const float* mean,
+                                     const float* rstd, float* dgamma, float* dbeta, void* dz,
+                                     void* workspace, pe_stream_t stream);
+
 /* Forward convolutions that also leave the batch-norm statistics of their own output behind,
  * so the training forward pass does not read z again to reduce it.  Same operands as
  * pe_conv2d_fwd_bf16 / pe_deconv4x4s2_fwd_bf16 / pe_stem7x7s2_fwd_bf16 with no epilogue

@@ -197,6 +197,15 @@ SIGNATURES = {
         c_int32,
         [c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p],
     ),
+    "pe_conv2d_bwd_data_bnmask_bf16": (
+        c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p,
+                  c_void_p, c_size_t, c_void_p, c_void_p]),
+    "pe_deconv4x4s2_bwd_data_bnmask_bf16": (
+        c_int32, [c_int32] * 5 + [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32,
+                                  c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
+    "pe_bn_bwd_from_partials_bf16": (
+        c_int32, [c_void_p, c_void_p, c_int32, c_int64, c_int32, c_void_p, c_void_p, c_void_p,
+                  c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "pe_bn_bwd_bf16": (
         c_int32,
         [c_void_p, c_void_p, c_int32, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p,

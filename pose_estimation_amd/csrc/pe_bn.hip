@@ -439,3 +439,35 @@ extern "C" int32_t pe_bn_bwd_bf16(const void* da, const void* a, int32_t relu, c
         act_scale, act_shift, static_cast<uint16_t*>(dz), static_cast<uint16_t*>(dmasked));
     return check_launch("pe_bn_bwd_bf16(apply)");
 }
+
+extern "C" int32_t pe_bn_bwd_from_partials_bf16(const void* g, const void* z, int32_t rows,
+                                                int64_t M, int32_t C, const float* gamma,
+                                                const float* mean, const float* rstd,
+                                                float* dgamma, float* dbeta, void* dz,
+                                                void* workspace, pe_stream_t stream) {
+    int32_t rc = bn_check("pe_bn_bwd_from_partials_bf16", M, C);
+    if (rc != PE_OK) return rc;
+    PE_REQUIRE(g && z && gamma && mean && rstd && dgamma && dbeta && dz && workspace && rows > 0,
+               PE_E_INVALID, "pe_bn_bwd_from_partials_bf16: NULL pointer or no rows");
+    PE_REQUIRE(aligned(g, 16) && aligned(z, 16) && aligned(dz, 16), PE_E_INVALID,
+               "pe_bn_bwd_from_partials_bf16: tensors must be 16-byte aligned");
+    const size_t cap = pe_bn_workspace_bytes(M, C) / ((size_t)C * sizeof(float));
+    PE_REQUIRE((size_t)rows * 2 + 3 <= cap, PE_E_INVALID,
+               "pe_bn_bwd_from_partials_bf16: %d rows do not fit the workspace of (M, C)", rows);
+    float* partial = static_cast<float*>(workspace);
+    float* coefA = partial + (size_t)rows * 2 * C;   // behind the rows the conv wrote
+    float* coefB = coefA + C;
+    float* coefC = coefB + C;
+    hipStream_t st = as_stream(stream);
+    bn_bwd_finalize_kernel<<<(C + kFoldCh - 1) / kFoldCh, 256, 0, st>>>(
+        partial, rows, C, (float)(1.0 / (double)M), gamma, mean, rstd, dgamma, dbeta, coefA, coefB,
+        coefC);
+    rc = check_launch("pe_bn_bwd_from_partials_bf16(finalize)");
+    if (rc != PE_OK) return rc;
+    const long nchunk = M * (C / 8);
+    // g is already masked: no activation operand
+    bn_bwd_apply_kernel<<<ew_grid(nchunk), 256, 0, st>>>(
+        static_cast<const uint16_t*>(g), nullptr, static_cast<const uint16_t*>(z), nchunk, C / 8,
+        mean, coefA, coefB, coefC, INFINITY, nullptr, nullptr, static_cast<uint16_t*>(dz), nullptr);
+    return check_launch("pe_bn_bwd_from_partials_bf16(apply)");
+}

@@ -7,6 +7,8 @@
 // The rest of the file is the small bandwidth-bound glue of the backward graph: weight
 // transposes, max-pool backward, the float32-NCHW -> bf16-NHWC hand-over of the loss gradient.
 #include "pe_common.h"
+#include <math.h>
+
 #include "pe_igemm.h"
 #include "pe_wgrad.h"
 
@@ -253,8 +255,40 @@ extern "C" int32_t pe_conv2d_bwd_data_narrow_layout(int32_t KH, int32_t KW, int3
     return PE_OK;
 }
 
-extern "C" int32_t pe_conv2d_bwd_data_bf16(const pe_conv_desc* d, const void* dy, const void* w_t,
-                                           const void* residual, void* dx, pe_stream_t stream) {
+// The consumer side of a fused batch-norm backward: dx is the gradient of an activation
+// a = act(z * scale + shift); the launch stores it masked by the activation and leaves the two
+// reductions batch-norm backward needs (sum g, sum g*z per channel) in the workspace.
+struct MaskReq {
+    const void* z;
+    const float* act_scale;
+    const float* act_shift;
+    int32_t relu;            // 1: ReLU, 2: ReLU6
+    void* workspace;
+    size_t bytes;
+    int32_t* rows_out;
+};
+
+static int32_t attach_mask(IgemmParams& p, const MaskReq* mr, const char* what) {
+    if (mr == nullptr) return PE_OK;
+    PE_REQUIRE(mr->z && mr->act_scale && mr->act_shift && mr->workspace && mr->rows_out,
+               PE_E_INVALID, "%s: NULL mask operand", what);
+    PE_REQUIRE(mr->relu == 1 || mr->relu == 2, PE_E_INVALID, "%s: relu must be 1 or 2", what);
+    PE_REQUIRE(aligned(mr->workspace, 16) && p.N % 8 == 0, PE_E_INVALID,
+               "%s: the fused mask needs an aligned workspace and Cin %% 8 == 0", what);
+    PE_REQUIRE(p.res == nullptr, PE_E_UNSUPPORTED, "%s: the fused mask takes no residual", what);
+    p.mask_z = static_cast<const uint16_t*>(mr->z);
+    p.mask_sc = mr->act_scale;
+    p.mask_sh = mr->act_shift;
+    p.mask_hi = mr->relu == 2 ? 6.0f : INFINITY;
+    p.stat_partial = static_cast<float*>(mr->workspace);
+    p.stat_capacity_rows = (long)(mr->bytes / ((size_t)2 * p.N * sizeof(float)));
+    p.stat_rows_out = mr->rows_out;
+    return PE_OK;
+}
+
+static int32_t conv2d_bwd_data_impl(const pe_conv_desc* d, const void* dy, const void* w_t,
+                                    const void* residual, void* dx, const MaskReq* mr,
+                                    pe_stream_t stream) {
     PE_REQUIRE(d != nullptr, PE_E_INVALID, "pe_conv2d_bwd_data_bf16: NULL descriptor");
     PE_REQUIRE(d->KH > 0 && d->KW > 0 && d->KH * d->KW <= kMaxTaps, PE_E_UNSUPPORTED,
                "pe_conv2d_bwd_data_bf16: filter %dx%d not supported", d->KH, d->KW);
@@ -355,12 +389,33 @@ extern "C" int32_t pe_conv2d_bwd_data_bf16(const pe_conv_desc* d, const void* dy
     p.OW = d->W;
     p.osy = p.osx = s;
     p.ldc = d->Cin;
-    return igemm_launch(p, st, "pe_conv2d_bwd_data_bf16");
+    if (mr) {
+        PE_REQUIRE(!need_zero, PE_E_UNSUPPORTED,
+                   "pe_conv2d_bwd_data_bnmask_bf16: every input parity must have a tap");
+        const int32_t rc = attach_mask(p, mr, "pe_conv2d_bwd_data_bnmask_bf16");
+        if (rc != PE_OK) return rc;
+    }
+    return igemm_launch(p, st, mr ? "pe_conv2d_bwd_data_bnmask_bf16" : "pe_conv2d_bwd_data_bf16");
 }
 
-extern "C" int32_t pe_deconv4x4s2_bwd_data_bf16(int32_t B, int32_t H, int32_t W, int32_t Cin,
-                                                int32_t Cout, const void* dy, const void* w_t,
-                                                void* dx, pe_stream_t stream) {
+extern "C" int32_t pe_conv2d_bwd_data_bf16(const pe_conv_desc* d, const void* dy, const void* w_t,
+                                           const void* residual, void* dx, pe_stream_t stream) {
+    return conv2d_bwd_data_impl(d, dy, w_t, residual, dx, nullptr, stream);
+}
+
+extern "C" int32_t pe_conv2d_bwd_data_bnmask_bf16(const pe_conv_desc* d, const void* dy,
+                                                  const void* w_t, const void* z,
+                                                  const float* act_scale, const float* act_shift,
+                                                  int32_t relu, void* g, void* bn_workspace,
+                                                  size_t workspace_bytes, int32_t* rows_out,
+                                                  pe_stream_t stream) {
+    const MaskReq mr{z, act_scale, act_shift, relu, bn_workspace, workspace_bytes, rows_out};
+    return conv2d_bwd_data_impl(d, dy, w_t, nullptr, g, &mr, stream);
+}
+
+static int32_t deconv_bwd_data_impl(int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout,
+                                    const void* dy, const void* w_t, void* dx, const MaskReq* mr,
+                                    pe_stream_t stream) {
     PE_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, PE_E_INVALID,
                "pe_deconv4x4s2_bwd_data_bf16: sizes must be positive");
     IgemmParams p;
@@ -393,7 +448,28 @@ extern "C" int32_t pe_deconv4x4s2_bwd_data_bf16(int32_t B, int32_t H, int32_t W,
     p.OH = H;
     p.OW = W;
     p.ldc = Cin;
-    return igemm_launch(p, as_stream(stream), "pe_deconv4x4s2_bwd_data_bf16");
+    const int32_t rc = attach_mask(p, mr, "pe_deconv4x4s2_bwd_data_bnmask_bf16");
+    if (rc != PE_OK) return rc;
+    return igemm_launch(p, as_stream(stream),
+                        mr ? "pe_deconv4x4s2_bwd_data_bnmask_bf16" : "pe_deconv4x4s2_bwd_data_bf16");
+}
+
+extern "C" int32_t pe_deconv4x4s2_bwd_data_bf16(int32_t B, int32_t H, int32_t W, int32_t Cin,
+                                                int32_t Cout, const void* dy, const void* w_t,
+                                                void* dx, pe_stream_t stream) {
+    return deconv_bwd_data_impl(B, H, W, Cin, Cout, dy, w_t, dx, nullptr, stream);
+}
+
+extern "C" int32_t pe_deconv4x4s2_bwd_data_bnmask_bf16(int32_t B, int32_t H, int32_t W,
+                                                       int32_t Cin, int32_t Cout, const void* dy,
+                                                       const void* w_t, const void* z,
+                                                       const float* act_scale,
+                                                       const float* act_shift, int32_t relu,
+                                                       void* g, void* bn_workspace,
+                                                       size_t workspace_bytes, int32_t* rows_out,
+                                                       pe_stream_t stream) {
+    const MaskReq mr{z, act_scale, act_shift, relu, bn_workspace, workspace_bytes, rows_out};
+    return deconv_bwd_data_impl(B, H, W, Cin, Cout, dy, w_t, g, &mr, stream);
 }
 
 extern "C" int32_t pe_conv2d_bwd_weight_bf16(const pe_conv_desc* d, const void* x, const void* dy,

@@ -50,6 +50,16 @@ struct IgemmParams {
     int32_t* stat_rows_out;   // host pointer
     int stat_ntm;             // filled in by igemm_launch
     int nt_store;             // filled in by igemm_launch: non-temporal output stores
+    // Fused batch-norm backward, first half (training, backward-data launches): when mask_z is
+    // set the result is the gradient da of an activation a = act(z * mask_sc + mask_sh) whose
+    // pre-norm tensor z is laid out like y.  The epilogue rebuilds a from z (same operations
+    // and rounding as the forward normalise pass), stores g = (0 < a < mask_hi) ? da : 0 and
+    // writes, per output channel and tile, sum g and sum g*z to stat_partial (same layout as the
+    // forward statistics).  Needs bf16 NHWC output, no scale/shift/residual/ReLU, equal phases.
+    const uint16_t* mask_z;
+    const float* mask_sc;
+    const float* mask_sh;
+    float mask_hi;            // +inf: ReLU, 6: ReLU6
     int32_t tap_info[kMaxTaps];  // dy | dx << 8 | slot << 16, packed by igemm_launch for the kernel
     // Optional phases (gridDim.y): phase i uses taps [ph_t0[i], ph_t0[i] + ph_T[i]), the row grid
     // ph_Ho[i] x ph_Wo[i], output offset (ph_ooy[i], ph_oox[i]) and weights w + ph_woff[i].

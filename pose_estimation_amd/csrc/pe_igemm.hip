@@ -56,7 +56,7 @@ __device__ __forceinline__ void fast_divmod(int m, int d, float inv_d, int& q, i
     r -= fix * d;
 }
 
-template <int BM, int BN, int WM, bool DB, bool PF, int MINB>
+template <int BM, int BN, int WM, bool DB, bool PF, int MINB, bool MASK = false>
 __global__ __launch_bounds__(WM * 128, MINB)
 __attribute__((amdgpu_waves_per_eu(MINB * WM / 2, MINB * WM / 2))) void igemm_kernel(const IgemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -268,6 +268,12 @@ __attribute__((amdgpu_waves_per_eu(MINB * WM / 2, MINB * WM / 2))) void igemm_ke
         const int n = n0 + chunk * 8;
         const int scol = tid % BN, sgrp = tid / BN;
         float st1 = 0.0f, st2 = 0.0f;   // running column sums of the fused statistics
+        // MASK: this thread's chunk of 8 channels keeps its own sums over the rows it stores
+        float ms1[MASK ? 8 : 1], ms2[MASK ? 8 : 1];
+        if constexpr (MASK) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) ms1[i] = ms2[i] = 0.0f;
+        }
         // outputs far larger than the caches are streamed past them (uniform)
         const bool nt_store = p.nt_store != 0;
 #pragma unroll
@@ -290,7 +296,14 @@ __attribute__((amdgpu_waves_per_eu(MINB * WM / 2, MINB * WM / 2))) void igemm_ke
             // the residual rows of every iteration are requested before the tile is staged, so
             // the loads are in flight across the LDS round trip instead of one per iteration
             uint4 rres[NPASS];
-            if (p.res) {
+            if constexpr (MASK) {   // the rows of z this thread will mask with
+#pragma unroll
+                for (int pass = 0; pass < NPASS; ++pass) {
+                    rres[pass] = make_uint4(0u, 0u, 0u, 0u);
+                    if (opixs[pass] >= 0 && n < p.N)
+                        rres[pass] = *reinterpret_cast<const uint4*>(p.mask_z + opixs[pass] * p.ldc + n);
+                }
+            } else if (p.res) {
 #pragma unroll
                 for (int pass = 0; pass < NPASS; ++pass) {
                     rres[pass] = make_uint4(0u, 0u, 0u, 0u);
@@ -347,7 +360,33 @@ __attribute__((amdgpu_waves_per_eu(MINB * WM / 2, MINB * WM / 2))) void igemm_ke
                     const f32x4 v0 = *reinterpret_cast<const f32x4*>(cs + pr * CP + chunk * 8);
                     const f32x4 v1 = *reinterpret_cast<const f32x4*>(cs + pr * CP + chunk * 8 + 4);
                     float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-                    if (p.res) {
+                    if constexpr (MASK) {
+                        const uint4 zv = rres[pass];
+                        const uint32_t zu[4] = {zv.x, zv.y, zv.z, zv.w};
+                        // scale and shift of this thread's 8 channels (n < N and N % 8 == 0 here);
+                        // re-read per pass from the cache rather than held across the epilogue
+                        const f32x4 c0 = *reinterpret_cast<const f32x4*>(p.mask_sc + n);
+                        const f32x4 c1 = *reinterpret_cast<const f32x4*>(p.mask_sc + n + 4);
+                        const f32x4 h0 = *reinterpret_cast<const f32x4*>(p.mask_sh + n);
+                        const f32x4 h1 = *reinterpret_cast<const f32x4*>(p.mask_sh + n + 4);
+                        const float msc8[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+                        const float msh8[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) {
+                            const float zf = bf16_bits_to_float((i & 1) ? (zu[i >> 1] >> 16)
+                                                                        : (zu[i >> 1] & 0xffffu));
+                            float a = zf * msc8[i] + msh8[i];
+                            a = fmaxf(a, 0.0f);
+                            if (p.mask_hi == 6.0f) a = fminf(a, 6.0f);
+                            a = bf16_bits_to_float(float_to_bf16_bits(a));
+                            const float g = (a > 0.0f && a < p.mask_hi)
+                                                ? bf16_bits_to_float(float_to_bf16_bits(v[i]))
+                                                : 0.0f;
+                            v[i] = g;
+                            ms1[i] += g;
+                            ms2[i] += g * zf;
+                        }
+                    } else if (p.res) {
                         const uint4 rv = rres[pass];
                         const uint32_t u[4] = {rv.x, rv.y, rv.z, rv.w};
 #pragma unroll
@@ -381,7 +420,7 @@ __attribute__((amdgpu_waves_per_eu(MINB * WM / 2, MINB * WM / 2))) void igemm_ke
             // Batch-norm statistics of what was just stored (the bf16-rounded tile): per column,
             // sum and sum of squares over the tile's rows, in a fixed order.  Rows past M hold
             // exact zeros (their inputs were the zero block and a BN conv has no bias).
-            if (p.stat_partial) {
+            if (!MASK && p.stat_partial) {
 #pragma unroll 8
                 for (int r = sgrp * RPG; r < (sgrp + 1) * RPG; ++r) {
                     const float v =
@@ -391,6 +430,26 @@ __attribute__((amdgpu_waves_per_eu(MINB * WM / 2, MINB * WM / 2))) void igemm_ke
                 }
             }
             __syncthreads();  // the staged half is consumed before the next one overwrites it
+        }
+        if constexpr (MASK) {
+            // per-thread sums -> [row group][2][BN] in LDS (the staged tile is consumed), folded
+            // over the row groups in order
+            float* mred = cs;   // RPP * 2 * BN = 16 * NT floats: lds_bytes() reserves them
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                mred[(prow * 2 + 0) * BN + chunk * 8 + i] = ms1[i];
+                mred[(prow * 2 + 1) * BN + chunk * 8 + i] = ms2[i];
+            }
+            __syncthreads();
+            for (int e = tid; e < 2 * BN; e += NT) {
+                const int sidx = e / BN, col = e % BN;
+                float t = 0.0f;
+                for (int g2 = 0; g2 < RPP; ++g2) t += mred[(g2 * 2 + sidx) * BN + col];
+                const int nn = n0 + col;
+                if (nn < p.N)
+                    p.stat_partial[((long)(ph * p.stat_ntm + tile_m) * 2 + sidx) * p.N + nn] = t;
+            }
+            return;
         }
         if (p.stat_partial) {
             sred[(sgrp * 2 + 0) * BN + scol] = st1;
@@ -441,15 +500,17 @@ __attribute__((amdgpu_waves_per_eu(MINB * WM / 2, MINB * WM / 2))) void igemm_ke
     }
 }
 
-template <int BM, int BN, bool DB>
+template <int BM, int BN, bool DB, int NT = 256, bool MASK = false>
 static constexpr size_t lds_bytes() {
     const size_t ktile = (size_t)(BM + BN) * ROWB * (DB ? 2 : 1);
     // epilogue half tile + the per-group column sums of the fused batch-norm statistics
     const size_t etile = (size_t)(BM / 2) * (BN + 4) * sizeof(float) + 2 * 512 * sizeof(float);
-    return ktile > etile ? ktile : etile;
+    const size_t mtile = MASK ? (size_t)NT * 16 * sizeof(float) : 0;  // masked sums per thread
+    const size_t m = ktile > etile ? ktile : etile;
+    return m > mtile ? m : mtile;
 }
 
-template <int BM, int BN, int WM, bool DB, bool PF, int MINB>
+template <int BM, int BN, int WM, bool DB, bool PF, int MINB, bool MASK = false>
 static int32_t launch_cfg(IgemmParams& p, long maxM, hipStream_t st, const char* what) {
     const long ntm = (maxM + BM - 1) / BM;
     p.stat_ntm = (int)ntm;
@@ -461,14 +522,14 @@ static int32_t launch_cfg(IgemmParams& p, long maxM, hipStream_t st, const char*
     }
     const long ntn = (p.N + BN - 1) / BN;
     const dim3 grid((unsigned)(ntm * ntn), (unsigned)p.nphase);
-    constexpr size_t lds = lds_bytes<BM, BN, DB>();
+    constexpr size_t lds = lds_bytes<BM, BN, DB, WM * 128, MASK>();
     if constexpr (lds > 64 * 1024) {
         static const hipError_t once = hipFuncSetAttribute(
-            reinterpret_cast<const void*>(&igemm_kernel<BM, BN, WM, DB, PF, MINB>),
+            reinterpret_cast<const void*>(&igemm_kernel<BM, BN, WM, DB, PF, MINB, MASK>),
             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)once;
     }
-    igemm_kernel<BM, BN, WM, DB, PF, MINB><<<grid, WM * 128, lds, st>>>(p);
+    igemm_kernel<BM, BN, WM, DB, PF, MINB, MASK><<<grid, WM * 128, lds, st>>>(p);
     return check_launch(what);
 }
 
@@ -519,6 +580,13 @@ int32_t igemm_launch(const IgemmParams& pin, hipStream_t st, const char* what) {
             PE_REQUIRE(p.ph_Ho[i] == p.ph_Ho[0] && p.ph_Wo[i] == p.ph_Wo[0], PE_E_UNSUPPORTED,
                        "%s: fused statistics need equally sized phases", what);
     }
+    if (p.mask_z) {
+        PE_REQUIRE(p.stat_partial && p.mask_sc && p.mask_sh, PE_E_INVALID,
+                   "%s: the fused activation mask needs scale, shift and a statistics workspace",
+                   what);
+        PE_REQUIRE(aligned(p.mask_z, 16) && aligned(p.mask_sc, 16) && aligned(p.mask_sh, 16),
+                   PE_E_INVALID, "%s: z, scale and shift must be 16-byte aligned", what);
+    }
     // the kernel's reciprocal-based index split needs quotients below 2^20
     PE_REQUIRE(p.B < (1 << 20) && maxM / p.B < (1L << 22), PE_E_UNSUPPORTED,
                "%s: batch or map size out of range", what);
@@ -555,6 +623,20 @@ int32_t igemm_launch(const IgemmParams& pin, hipStream_t st, const char* what) {
         minb == MINB_) {                                                               \
         return launch_cfg<BM_, BN_, WM_, DB_, PF_, MINB_>(p, maxM, st, what);          \
     }
+#define PE_CFG_MASK(BM_, BN_, WM_, DB_, PF_, MINB_)                                   \
+    if (p.mask_z && bm == BM_ && bn == BN_ && wm == WM_ && db == (DB_ ? 1 : 0) &&     \
+        pf == (PF_ ? 1 : 0) && minb == MINB_) {                                        \
+        return launch_cfg<BM_, BN_, WM_, DB_, PF_, MINB_, true>(p, maxM, st, what);    \
+    }
+    PE_CFG_MASK(128, 128, 2, false, false, 4)
+    PE_CFG_MASK(128, 64, 2, false, false, 4)
+    PE_CFG_MASK(64, 128, 2, false, false, 4)
+    PE_CFG_MASK(64, 64, 2, false, false, 4)
+    PE_CFG_MASK(128, 32, 2, false, false, 4)
+    PE_CFG_MASK(64, 32, 2, false, false, 4)
+    PE_CFG_MASK(64, 64, 2, true, false, 2)
+#undef PE_CFG_MASK
+    PE_REQUIRE(!p.mask_z, PE_E_UNSUPPORTED, "%s: no masked kernel for tile %dx%d", what, bm, bn);
     PE_CFG(128, 128, 2, false, false, 4)
     PE_CFG(128, 64, 2, false, false, 4)
     PE_CFG(64, 128, 2, false, false, 4)

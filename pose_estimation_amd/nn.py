@@ -581,6 +581,78 @@ def conv2d_bwd_data(dy: torch.Tensor, w_t: torch.Tensor, in_hw, k: int, stride: 
     return out
 
 
+def conv2d_bwd_data_bnmask(dy: torch.Tensor, w_t: torch.Tensor, in_hw, k: int, stride: int,
+                           pad: int, z: torch.Tensor, act_scale: torch.Tensor,
+                           act_shift: torch.Tensor, ws: torch.Tensor, relu: int = 1,
+                           out: Optional[torch.Tensor] = None):
+    """conv2d_bwd_data whose result is the gradient of a = act(z * act_scale + act_shift): stores
+    it masked by the activation and leaves the partial rows of batch-norm backward's two sums in
+    `ws`; returns (g, rows) for bn_bwd_from_partials."""
+    _check_act(dy, "dy")
+    _check_act(z, "z")
+    B, Ho, Wo, Cout = dy.shape
+    Cin = w_t.shape[0]
+    H, W = in_hw
+    if tuple(z.shape) != (B, H, W, Cin):
+        raise ValueError(f"z must be [B,H,W,Cin] = {(B, H, W, Cin)}")
+    if Cout in (8, 16, 32):
+        nslots = narrow_bwd_layout(k, stride, pad, Cout)[2]
+        if tuple(w_t.shape) != (Cin, nslots, 64) or w_t.dtype != BF16:
+            raise ValueError(f"narrow w_t must be bfloat16 [Cin, {nslots}, 64]")
+    elif tuple(w_t.shape) != (Cin, k * k, Cout) or w_t.dtype != BF16:
+        raise ValueError("w_t must be bfloat16 [Cin, k*k, Cout]")
+    if out is None:
+        out = torch.empty((B, H, W, Cin), dtype=BF16, device=dy.device)
+    d = ConvDesc(B, H, W, Cin, Cout, k, k, stride, pad, 0, 0)
+    rows = ctypes.c_int32(0)
+    with on_device(dy):
+        check(lib().pe_conv2d_bwd_data_bnmask_bf16(
+            ctypes.addressof(d), dy.data_ptr(), w_t.data_ptr(), z.data_ptr(), act_scale.data_ptr(),
+            act_shift.data_ptr(), int(relu), out.data_ptr(), ws.data_ptr(), ws.numel(),
+            ctypes.byref(rows), _stream(dy)))
+    return out, rows.value
+
+
+def deconv4x4s2_bwd_data_bnmask(dy: torch.Tensor, w_t: torch.Tensor, z: torch.Tensor,
+                                act_scale: torch.Tensor, act_shift: torch.Tensor,
+                                ws: torch.Tensor, relu: int = 1,
+                                out: Optional[torch.Tensor] = None):
+    """deconv4x4s2_bwd_data with the fused activation mask and sums (see conv2d_bwd_data_bnmask)."""
+    _check_act(dy, "dy")
+    _check_act(z, "z")
+    B, H2, W2, Cout = dy.shape
+    Cin = w_t.shape[0]
+    if tuple(z.shape) != (B, H2 // 2, W2 // 2, Cin):
+        raise ValueError("z must be [B,H,W,Cin]")
+    if out is None:
+        out = torch.empty((B, H2 // 2, W2 // 2, Cin), dtype=BF16, device=dy.device)
+    rows = ctypes.c_int32(0)
+    with on_device(dy):
+        check(lib().pe_deconv4x4s2_bwd_data_bnmask_bf16(
+            B, H2 // 2, W2 // 2, Cin, Cout, dy.data_ptr(), w_t.data_ptr(), z.data_ptr(),
+            act_scale.data_ptr(), act_shift.data_ptr(), int(relu), out.data_ptr(), ws.data_ptr(),
+            ws.numel(), ctypes.byref(rows), _stream(dy)))
+    return out, rows.value
+
+
+def bn_bwd_from_partials(g: torch.Tensor, z: torch.Tensor, rows: int, gamma, mean, rstd, dgamma,
+                         dbeta, ws: torch.Tensor, dz=None) -> torch.Tensor:
+    """Second half of the fused batch-norm backward: folds the `rows` partial rows a *_bnmask
+    backward-data call left in `ws` and returns dz."""
+    _check_act(g, "g")
+    C = z.shape[3]
+    M = z.numel() // C
+    if dz is None:
+        dz = torch.empty_like(z)
+    with on_device(z):
+        check(lib().pe_bn_bwd_from_partials_bf16(g.data_ptr(), z.data_ptr(), int(rows), M, C,
+                                                 gamma.data_ptr(), mean.data_ptr(),
+                                                 rstd.data_ptr(), dgamma.data_ptr(),
+                                                 dbeta.data_ptr(), dz.data_ptr(), ws.data_ptr(),
+                                                 _stream(z)))
+    return dz
+
+
 def deconv4x4s2_bwd_data(dy: torch.Tensor, w_t: torch.Tensor,
                          out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """dx [B,H,W,Cin] from dy [B,2H,2W,Cout] and w_t [Cin,16,Cout]."""

@@ -9,6 +9,7 @@ parallelism (test.ipynb:12): local batch statistics, summed gradients averaged o
 """
 from __future__ import annotations
 
+import os
 from contextlib import contextmanager
 from typing import Dict, List, Optional
 
@@ -56,6 +57,9 @@ class TrainablePoseResNet(PoseResNet):
         self.layer_starts: List[int] = [self.offsets[c.name + ".weight"][0] for c in self.convs]
         self.bucketer: Optional[GradBucketer] = None
         self.saved: dict = {}
+        # backward-data GEMMs mask their result and reduce it for the batch norm below them
+        # (PE_FUSE_BN_BWD=0: the separate reduction pass, for comparison)
+        self.fuse_bn_bwd = os.environ.get("PE_FUSE_BN_BWD", "1") != "0"
         # Weight gradients run on their own stream: they depend only on a layer's input and its
         # output gradient, nothing downstream reads them before the optimizer, and at batch 64
         # many backward kernels leave CUs idle, so they fill in beside the backward-data chain.
@@ -166,13 +170,19 @@ class TrainablePoseResNet(PoseResNet):
                 pnn.conv2d_bwd_weight(s["a2"], dz3, self._g(b.c3.name + ".weight"), 1, 1, 0)
                 self._done(b.c3)
             res = g3
-        da2 = pnn.conv2d_bwd_data(dz3, self.wt[b.c3.name], tuple(s["a2"].shape[1:3]), 1, 1, 0)
-        dz2, _ = self._bn_bwd(b.c2, da2, s["a2"], s["z2"], rebuild=True)
+        if self.fuse_bn_bwd:
+            dz2 = self._bwd_data_bn(b.c2, s["z2"], dz3, self.wt[b.c3.name], 1, 1, 0)
+        else:
+            da2 = pnn.conv2d_bwd_data(dz3, self.wt[b.c3.name], tuple(s["a2"].shape[1:3]), 1, 1, 0)
+            dz2, _ = self._bn_bwd(b.c2, da2, s["a2"], s["z2"], rebuild=True)
         with self._beside(s["a1"], dz2):
             pnn.conv2d_bwd_weight(s["a1"], dz2, self._g(b.c2.name + ".weight"), 3, b.c2.stride, 1)
             self._done(b.c2)
-        da1 = pnn.conv2d_bwd_data(dz2, self.wt[b.c2.name], hw_mid, 3, b.c2.stride, 1)
-        dz1, _ = self._bn_bwd(b.c1, da1, s["a1"], s["z1"], rebuild=True)
+        if self.fuse_bn_bwd and hw_mid[0] % b.c2.stride == 0 and hw_mid[1] % b.c2.stride == 0:
+            dz1 = self._bwd_data_bn(b.c1, s["z1"], dz2, self.wt[b.c2.name], 3, b.c2.stride, 1)
+        else:
+            da1 = pnn.conv2d_bwd_data(dz2, self.wt[b.c2.name], hw_mid, 3, b.c2.stride, 1)
+            dz1, _ = self._bn_bwd(b.c1, da1, s["a1"], s["z1"], rebuild=True)
         with self._beside(x, dz1):
             pnn.conv2d_bwd_weight(x, dz1, self._g(b.c1.name + ".weight"), 1, 1, 0)
             self._done(b.c1)
@@ -227,6 +237,29 @@ class TrainablePoseResNet(PoseResNet):
                           act_scale=buf[2] if rebuild else None,
                           act_shift=buf[3] if rebuild else None)
 
+    def _bwd_data_bn(self, below: ConvSpec, z_below: torch.Tensor, dy: torch.Tensor,
+                     wt: torch.Tensor, k: int, stride: int, pad: int) -> torch.Tensor:
+        """Backward-data of a conv whose input is the ReLU output of layer `below` (no residual,
+        no other consumer), straight to dz of `below`: the GEMM masks its result with the
+        activation rebuilt from z_below and leaves batch-norm backward's sums behind, so the
+        gradient is not read again to reduce it."""
+        buf = self.bn_rows[below.name]
+        ws = self._workspace(z_below)
+        g, rows = pnn.conv2d_bwd_data_bnmask(dy, wt, tuple(z_below.shape[1:3]), k, stride, pad,
+                                             z_below, buf[2], buf[3], ws)
+        return pnn.bn_bwd_from_partials(g, z_below, rows, self._gamma(below), buf[0], buf[1],
+                                        self._g(below.name + ".bn.gamma"),
+                                        self._g(below.name + ".bn.beta"), ws)
+
+    def _deconv_bwd_data_bn(self, below: ConvSpec, z_below: torch.Tensor, dy: torch.Tensor,
+                            wt: torch.Tensor) -> torch.Tensor:
+        buf = self.bn_rows[below.name]
+        ws = self._workspace(z_below)
+        g, rows = pnn.deconv4x4s2_bwd_data_bnmask(dy, wt, z_below, buf[2], buf[3], ws)
+        return pnn.bn_bwd_from_partials(g, z_below, rows, self._gamma(below), buf[0], buf[1],
+                                        self._g(below.name + ".bn.gamma"),
+                                        self._g(below.name + ".bn.beta"), ws)
+
     def _done(self, c: ConvSpec) -> None:
         if self.bucketer is not None:
             self.bucketer.layer_done(self.offsets[c.name + ".weight"][0])
@@ -258,10 +291,27 @@ class TrainablePoseResNet(PoseResNet):
                                   cout=final.cout)
             self._done(final)
         H, W = sv["feat"].shape[1:3]
-        dx = pnn.conv2d_bwd_data(dyp, self.wt[final.name], (H, W), 1, 1, 0)
-        # deconv head
-        for d, s in zip(reversed(deconvs), reversed(sv["deconvs"])):
-            dx = self.deconv_backward(d, s, dx)
+        # deconv head.  With the fused batch-norm backward every backward-data GEMM of the chain
+        # hands the layer below its dz directly (mask and sums in the GEMM epilogue).
+        dz = None
+        if self.fuse_bn_bwd and deconvs:
+            dz = self._bwd_data_bn(deconvs[-1], sv["deconvs"][-1]["z"], dyp, self.wt[final.name],
+                                   1, 1, 0)
+        else:
+            dx = pnn.conv2d_bwd_data(dyp, self.wt[final.name], (H, W), 1, 1, 0)
+        for i in reversed(range(len(deconvs))):
+            d, s = deconvs[i], sv["deconvs"][i]
+            if dz is None:
+                dz, _ = self._bn_bwd(d, dx, s["a"], s["z"], rebuild=True)
+            with self._beside(s["x"], dz):
+                pnn.deconv4x4s2_bwd_weight(s["x"], dz, self._g(d.name + ".weight"))
+                self._done(d)
+            if self.fuse_bn_bwd and i > 0:
+                dz = self._deconv_bwd_data_bn(deconvs[i - 1], sv["deconvs"][i - 1]["z"], dz,
+                                              self.wt[d.name])
+            else:
+                dx = pnn.deconv4x4s2_bwd_data(dz, self.wt[d.name])
+                dz = None
         # bottleneck blocks
         for b, s in zip(reversed(blocks), reversed(sv["blocks"])):
             dx = self.block_backward(b, s, dx)

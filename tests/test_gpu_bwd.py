@@ -506,3 +506,102 @@ def test_depthwise_backward(case):
     assert torch.equal(dw.cpu(), wt_.grad.reshape(C, 9).t())
     pnn.depthwise3x3_bwd_weight(x.to(BF16).cuda(), dy.to(BF16).cuda(), dw, s, d)   # accumulates
     assert torch.equal(dw.cpu(), 2 * wt_.grad.reshape(C, 9).t())
+
+
+# ------------------------------------------------------------- fused batch-norm backward (mask + sums)
+def _bn_rows(z, C, g):
+    """Per-channel rows a forward pass would have left: mean, rstd, scale, shift."""
+    gamma = (torch.rand(C, generator=g) + 0.5).cuda()
+    beta = (torch.randn(C, generator=g) * 0.3).cuda()
+    ws = pnn.bn_workspace(z.numel() // C, C, "cuda")
+    mean, rstd, scale, shift = pnn.bn_stats(z, gamma, beta, 1e-5, 0.1, None, None, ws)
+    return gamma, mean, rstd, scale, shift, ws
+
+
+def _check_fused(g_f, dz_f, dg_f, db_f, g_r, dz_r, dg_r, db_r):
+    assert torch.equal(g_f, g_r)                         # the masked gradient, bit for bit
+    rel = lambda a, b: ((a - b).norm() / (b.norm() + 1e-30)).item()  # noqa: E731
+    assert rel(dg_f, dg_r) < 1e-5 and rel(db_f, db_r) < 1e-5          # summation order only
+    d = (dz_f.float() - dz_r.float()).abs()
+    # coefficients differ in their last bits, so a few dz land on the neighbouring bf16 value
+    assert d.max().item() <= 8e-3 * dz_r.float().abs().max().item()
+    assert (d > 0).float().mean().item() < 0.02
+
+
+FUSED_BWD_CASES = [
+    # B, H, W, Cin, Cout, k, stride, pad, relu
+    (2, 16, 12, 64, 256, 1, 1, 0, 1),      # conv3 of a bottleneck -> conv2's batch norm
+    (3, 16, 12, 128, 128, 3, 1, 1, 1),     # conv2 -> conv1's batch norm
+    (3, 16, 12, 128, 128, 3, 2, 1, 1),     # stride 2: four input-parity phases
+    (2, 20, 20, 192, 64, 1, 1, 0, 2),      # ReLU6 (pointwise projection -> depthwise batch norm)
+    (2, 24, 20, 256, 32, 1, 1, 0, 1),      # narrow gradient operand (final conv -> last deconv)
+    (5, 64, 48, 64, 64, 3, 1, 1, 1),       # many tiles
+]
+
+
+@pytest.mark.parametrize("case", FUSED_BWD_CASES)
+def test_bwd_data_with_fused_mask_and_sums_equals_the_separate_passes(case):
+    B, H, W, Cin, Cout, k, s, p, relu = case
+    g = torch.Generator().manual_seed(61 + sum(case))
+    Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    z = rnd((B, H, W, Cin), g).to(BF16).cuda()
+    dy = rnd((B, Ho, Wo, Cout), g).to(BF16).cuda()
+    w = rnd((Cout, Cin, k, k), g, (1.0 / (Cout * k * k)) ** 0.5)
+    if Cout in (8, 16, 32):
+        w_t = planned_wt(w, k, s, p)
+    else:
+        w_t = conv_wt(w)
+    gamma, mean, rstd, scale, shift, ws = _bn_rows(z, Cin, g)
+    if relu == 2:
+        scale, shift = scale * 3.0, shift + 3.0      # spreads a over (0, 6) and beyond
+    da = pnn.conv2d_bwd_data(dy, w_t, (H, W), k, s, p)
+    dg_r, db_r = torch.empty(Cin, device="cuda"), torch.empty(Cin, device="cuda")
+    dz_r, g_r = pnn.bn_bwd(da, None, z, gamma, mean, rstd, dg_r, db_r, ws, want_masked=True,
+                           relu=relu, act_scale=scale, act_shift=shift)
+    g_r, dz_r = g_r.clone(), dz_r.clone()
+    frac = (g_r == 0).float().mean().item()
+    assert 0.15 < frac < 0.9                              # the mask does something
+    ws2 = pnn.bn_workspace(B * H * W, Cin, "cuda")
+    ws2.fill_(0xFF)                                       # NaN patterns: every row must be written
+    dg_f, db_f = torch.empty(Cin, device="cuda"), torch.empty(Cin, device="cuda")
+    g_f, rows = pnn.conv2d_bwd_data_bnmask(dy, w_t, (H, W), k, s, p, z, scale, shift, ws2, relu)
+    assert rows >= 1
+    dz_f = pnn.bn_bwd_from_partials(g_f, z, rows, gamma, mean, rstd, dg_f, db_f, ws2)
+    _check_fused(g_f, dz_f, dg_f, db_f, g_r, dz_r, dg_r, db_r)
+
+
+@pytest.mark.parametrize("case", [(2, 8, 6, 256, 256), (3, 16, 12, 512, 256)])
+def test_deconv_bwd_data_with_fused_mask_and_sums(case):
+    B, H, W, Cin, Cout = case
+    g = torch.Generator().manual_seed(71 + Cin)
+    z = rnd((B, H, W, Cin), g).to(BF16).cuda()
+    dy = rnd((B, 2 * H, 2 * W, Cout), g).to(BF16).cuda()
+    w = rnd((Cin, Cout, 4, 4), g, (1.0 / (Cout * 4)) ** 0.5)
+    wp = pnn.pack_deconv_weight(w).cuda()
+    w_t = torch.zeros(Cin, 16, Cout, dtype=BF16, device="cuda")
+    for ph in range(4):
+        pnn.transpose_weights(wp[ph], w_t, t0=4 * ph)
+    gamma, mean, rstd, scale, shift, ws = _bn_rows(z, Cin, g)
+    da = pnn.deconv4x4s2_bwd_data(dy, w_t)
+    dg_r, db_r = torch.empty(Cin, device="cuda"), torch.empty(Cin, device="cuda")
+    dz_r, g_r = pnn.bn_bwd(da, None, z, gamma, mean, rstd, dg_r, db_r, ws, want_masked=True,
+                           act_scale=scale, act_shift=shift)
+    g_r, dz_r = g_r.clone(), dz_r.clone()
+    ws2 = pnn.bn_workspace(B * H * W, Cin, "cuda")
+    ws2.fill_(0xFF)
+    dg_f, db_f = torch.empty(Cin, device="cuda"), torch.empty(Cin, device="cuda")
+    g_f, rows = pnn.deconv4x4s2_bwd_data_bnmask(dy, w_t, z, scale, shift, ws2)
+    dz_f = pnn.bn_bwd_from_partials(g_f, z, rows, gamma, mean, rstd, dg_f, db_f, ws2)
+    _check_fused(g_f, dz_f, dg_f, db_f, g_r, dz_r, dg_r, db_r)
+
+
+def test_fused_mask_argument_errors():
+    z = torch.zeros(1, 8, 8, 64, dtype=BF16, device="cuda")
+    dy = torch.zeros(1, 4, 4, 64, dtype=BF16, device="cuda")
+    w_t = torch.zeros(64, 1, 64, dtype=BF16, device="cuda")
+    sc = torch.ones(64, device="cuda")
+    ws = pnn.bn_workspace(64, 64, "cuda")
+    with pytest.raises(Exception):     # 1x1 stride 2: three input parities have no tap
+        pnn.conv2d_bwd_data_bnmask(dy, w_t, (8, 8), 1, 2, 0, z, sc, sc, ws)
+    with pytest.raises(Exception):     # relu must say which activation
+        pnn.conv2d_bwd_data_bnmask(torch.zeros_like(z), w_t, (8, 8), 1, 1, 0, z, sc, sc, ws, relu=0)
