@@ -18,6 +18,7 @@ folded-BN kernels and records nothing.
 """
 from __future__ import annotations
 
+import os
 from contextlib import contextmanager
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Sequence, Tuple
@@ -89,12 +90,15 @@ class Layer:
 
 class Var:
     """An activation and, during backward, the gradient accumulated for it so far."""
-    __slots__ = ("t", "grad", "needs_grad")
+    __slots__ = ("t", "grad", "needs_grad", "consumers", "prod", "dz")
 
     def __init__(self, t: torch.Tensor, needs_grad: bool = True):
         self.t = t
         self.grad: Optional[torch.Tensor] = None
         self.needs_grad = needs_grad
+        self.consumers = 0      # layers that read this activation in the current forward pass
+        self.prod = None        # (layer, z, act) when it is act(bn(z)) with no residual
+        self.dz = None          # gradient of that z, when the consumer's backward-data made it
 
 
 def _align8(n: int) -> int:
@@ -166,6 +170,12 @@ class TrainGraph:
         # reads them before the optimizer: they run beside the backward-data chain
         self.wgrad_stream: Optional[torch.cuda.Stream] = torch.cuda.Stream(device=dev)
         self._keep: list = []
+        # backward-data GEMMs mask their result and reduce it for the batch norm below them
+        # whenever that layer's output has no other reader (PE_FUSE_BN_BWD=0: separate passes)
+        self.fuse_bn_bwd = os.environ.get("PE_FUSE_BN_BWD", "1") != "0"
+        # ... when the GEMM's reduction is long enough to carry the heavier epilogue: with a
+        # short one (a pointwise conv from 64 channels) the separate pass measured faster
+        self.fuse_min_k = int(os.environ.get("PE_FUSE_MIN_K", "256"))
         self._pending_wg: list = []
         self._step_graphs: Dict[tuple, "StepGraph"] = {}
 
@@ -273,6 +283,9 @@ class TrainGraph:
                                L.stride, L.pad, act, **kw)
             return Var(y, False)
         B, H, W, _ = x.t.shape
+        x.consumers += 1
+        if residual is not None:
+            residual.consumers += 1
         gamma = self.view(self.master, L.name + ".bn.gamma")
         beta = self.view(self.master, L.name + ".bn.beta")
         if L.kind == "dw":
@@ -283,6 +296,8 @@ class TrainGraph:
                                               self.bn_mean[L.name], self.bn_var[L.name],
                                               self._workspace_for(M, L.cout), out=self.bn_buf[L.name])
             out = Var(pnn.bn_apply(z, scale, shift, res_t, act))
+            if act and residual is None:
+                out.prod = (L, z, act)
             self.tape.append(("unit", L, x, residual, act, z, out))
             return out
         if L.kind == "stem3":
@@ -298,6 +313,8 @@ class TrainGraph:
             self._ws, rows, M, L.cout, gamma, beta, BN_EPS, self.bn_momentum,
             self.bn_mean[L.name], self.bn_var[L.name], out=self.bn_rows[L.name])
         out = Var(pnn.bn_apply(z, scale, shift, res_t, act))
+        if act and residual is None:
+            out.prod = (L, z, act)
         self.tape.append(("unit", L, x, residual, act, z, out))
         return out
 
@@ -307,6 +324,9 @@ class TrainGraph:
         y = pnn.fuse_upsample_add(base.t, [v.t for v in lows], list(log2_factors), relu=relu)
         out = Var(y, self.training)
         if self.training:
+            base.consumers += 1
+            for v in lows:
+                v.consumers += 1
             self.tape.append(("fuse", base, list(lows), list(log2_factors), relu, out))
         return out
 
@@ -316,6 +336,7 @@ class TrainGraph:
         y = pnn.conv2d(x.t, self.w(L), None, self.view(self.master, L.name + ".bias"),
                        out_f32_nchw=True, **kw)
         if self.training:
+            x.consumers += 1
             self.tape.append(("head", L, x))
         return y
 
@@ -387,6 +408,23 @@ class TrainGraph:
             dx = pnn.depthwise3x3_bwd_data(dz, self.w(L), hw, L.stride, L.dilation)
             x.grad = dx if x.grad is None else pnn.add_bf16(x.grad, dx)
             return
+        if (self.fuse_bn_bwd and x.prod is not None and x.consumers == 1 and x.grad is None
+                and L.k * L.k * L.cout >= self.fuse_min_k
+                and not (L.k == 1 and L.stride == 2)
+                and hw[0] % L.stride == 0 and hw[1] % L.stride == 0):
+            # x = act(bn(z)) read by this layer alone: the GEMM masks its result with the
+            # activation rebuilt from z and reduces batch-norm backward's sums, so the layer
+            # below gets its dz without reading the gradient again
+            Lb, zb, actb = x.prod
+            buf = self.bn_rows[Lb.name]
+            ws = self._workspace_for(zb.numel() // Lb.cout, Lb.cout)
+            g, rows = pnn.conv2d_bwd_data_bnmask(dz, self.wt[L.name], hw, L.k, L.stride, L.pad,
+                                                 zb, buf[2], buf[3], ws, relu=actb)
+            x.dz = pnn.bn_bwd_from_partials(
+                g, zb, rows, self.view(self.master, Lb.name + ".bn.gamma"), buf[0], buf[1],
+                self._g(Lb.name + ".bn.gamma"), self._g(Lb.name + ".bn.beta"), ws)
+            x.grad = g
+            return
         fused = x.grad is not None and not (L.k == 1 and L.stride == 2)
         dx = pnn.conv2d_bwd_data(dz, self.wt[L.name], hw, L.k, L.stride, L.pad,
                                  residual=x.grad if fused else None)
@@ -422,6 +460,14 @@ class TrainGraph:
                 _, L, x, residual, act, z, out = rec
                 if out.grad is None:
                     raise RuntimeError(f"layer {L.name}: output received no gradient")
+                if out.dz is not None:       # made by the consumer's backward-data GEMM
+                    dz = out.dz
+                    out.dz = None
+                    out.grad = None
+                    self._weight_grad(L, x.t, dz)
+                    if L.kind != "stem3":
+                        self._data_grad(L, x, dz)
+                    continue
                 buf = self.bn_rows[L.name]
                 masked = residual is not None and act != 0
                 # without a residual the activation mask is rebuilt from z (scale and shift of the
