@@ -15,12 +15,18 @@ from typing import List, Optional, Sequence, Tuple
 import torch
 
 
-def make_buckets(boundaries: Sequence[int], total: int, bucket_elems: int) -> List[Tuple[int, int]]:
+def make_buckets(boundaries: Sequence[int], total: int, bucket_elems: int,
+                 tail_elems: Optional[int] = None) -> List[Tuple[int, int]]:
     """Cut [0, total) at layer boundaries into buckets of about `bucket_elems` elements.
 
     boundaries: ascending start offsets of the layers (first must be 0).  Buckets are returned
     in REVERSE arena order (the order backward completes them); every bucket is a whole number
     of layers and the buckets tile [0, total) exactly.
+
+    tail_elems: the bucket backward completes LAST (the first layers of the network) cannot
+    overlap anything: its all-reduce is exposed in full before the optimizer.  When given, that
+    bucket is cut down to about tail_elems elements and the rest of it becomes a bucket of its
+    own, which is reduced while the first layers are still being differentiated.
     """
     if not boundaries or boundaries[0] != 0:
         raise ValueError("boundaries must start at 0")
@@ -37,6 +43,13 @@ def make_buckets(boundaries: Sequence[int], total: int, bucket_elems: int) -> Li
         buckets.append((start, end))
         end = start
         i -= 1
+    if tail_elems is not None and buckets:
+        lo, hi = buckets[-1]
+        inner = [c for c in boundaries if lo < c < hi and c - lo >= tail_elems]
+        if inner:
+            cut = inner[0]
+            buckets[-1] = (cut, hi)
+            buckets.append((lo, cut))
     return buckets
 
 
@@ -44,7 +57,7 @@ class GradBucketer:
     """Issues one all-reduce per bucket as backward passes the bucket's lowest layer."""
 
     def __init__(self, arena: torch.Tensor, boundaries: Sequence[int],
-                 bucket_bytes: int = 32 << 20, group=None):
+                 bucket_bytes: int = 32 << 20, group=None, tail_bytes: Optional[int] = None):
         import torch.distributed as dist
 
         self.dist = dist
@@ -58,7 +71,10 @@ class GradBucketer:
         backend = dist.get_backend(group) if dist.is_initialized() else "none"
         self._staged = backend == "gloo" and arena.is_cuda
         elems = max(1, bucket_bytes // arena.element_size())
-        self.buckets = make_buckets(boundaries, arena.numel(), elems)
+        if tail_bytes is None:
+            tail_bytes = bucket_bytes // 8
+        self.buckets = make_buckets(boundaries, arena.numel(), elems,
+                                    max(1, tail_bytes // arena.element_size()))
         self._ready_at = {start: (start, end) for (start, end) in self.buckets}
         self._pending: List = []
 

@@ -24,6 +24,11 @@ def test_buckets_tile_the_arena_in_reverse_order():
     assert make_buckets(bounds, total, 1) == [(1800, 2000), (1000, 1800), (900, 1000), (260, 900),
                                               (250, 260), (100, 250), (0, 100)]
     assert make_buckets(bounds, total, 10**9) == [(0, 2000)]
+    # a short tail: the bucket that finishes last is cut at the first layer start that leaves it
+    # at least tail_elems long; everything still tiles the arena in descending order
+    assert make_buckets(bounds, total, 10**9, 200) == [(250, 2000), (0, 250)]
+    assert make_buckets(bounds, total, 500, 90) == [(1000, 2000), (260, 1000), (100, 260), (0, 100)]
+    assert make_buckets(bounds, total, 500, 10**9) == make_buckets(bounds, total, 500)
 
 
 def test_real_model_layout_buckets():
@@ -44,6 +49,10 @@ def test_real_model_layout_buckets():
     assert sum(e - s for s, e in b) == off
     assert 3 <= len(b) <= 20
     assert 34.0e6 < off < 34.2e6
+    # the all-reduce nothing can hide (stem and the first blocks) is about 4 MB instead of 32
+    bt = make_buckets(starts, off, (32 << 20) // 4, (4 << 20) // 4)
+    assert sum(e - s for s, e in bt) == off and len(bt) == len(b) + 1
+    assert (4 << 20) // 4 <= bt[-1][1] - bt[-1][0] < (8 << 20) // 4 and bt[-1][0] == 0
 
 
 def _free_port():
