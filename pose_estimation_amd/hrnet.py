@@ -21,6 +21,7 @@ Activations are NHWC bf16; BN is folded into per-channel float32 scale and shift
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional
 
@@ -208,6 +209,17 @@ class PoseHRNet:
         self.device = torch.device(device)
         self.spec = hrnet_specs(num_joints, width, modules, blocks, layer1_blocks)
         self.p: Dict[str, torch.Tensor] = {}
+        # The branches of an exchange module are independent chains of small launches (the
+        # low-resolution ones fill a fraction of the chip): each branch but the first runs on a
+        # stream of its own and the module joins them before its fusion layers.
+        # PE_HRNET_BRANCH_STREAMS=0: one stream, for comparison.
+        self._side: List[torch.cuda.Stream] = []
+        self.branch_streams = os.environ.get("PE_HRNET_BRANCH_STREAMS", "1") != "0"
+
+    def _side_streams(self, n: int) -> List[torch.cuda.Stream]:
+        while len(self._side) < n:
+            self._side.append(torch.cuda.Stream(self.device))
+        return self._side[:n]
 
     # ------------------------------------------------------------------ parameters
     def _pack(self, w: torch.Tensor) -> torch.Tensor:
@@ -240,29 +252,58 @@ class PoseHRNet:
         return pnn.conv2d(x, p[u.name + ".weight"], p[u.name + ".scale"], p[u.name + ".shift"],
                           residual, u.stride, u.k // 2, u.relu if relu is None else relu, kw=u.k)
 
+    def _branch(self, x: torch.Tensor, br) -> torch.Tensor:
+        for blk in br:
+            x = self._unit(blk.c2, self._unit(blk.c1, x), residual=x, relu=True)
+        return x
+
     def _module(self, m: Module, xs: List[torch.Tensor]) -> List[torch.Tensor]:
-        ys = []
-        for x, br in zip(xs, m.branches):
-            for blk in br:
-                x = self._unit(blk.c2, self._unit(blk.c1, x), residual=x, relu=True)
-            ys.append(x)
-        outs = []
-        for i, row in enumerate(m.fuse):
-            lows = [(j, row[j]) for j in range(len(row)) if j > i]
-            s = ys[i]
-            for j in range(i):
-                t = ys[j]
-                chain = row[j]
-                for u in chain[:-1]:
-                    t = self._unit(u, t)
-                # the last conv of the chain adds the running sum; it also rectifies when
-                # nothing else follows
-                s = self._unit(chain[-1], t, residual=s, relu=(j == i - 1 and not lows))
-            if lows:
-                proj = [self._unit(chain[0], ys[j]) for j, chain in lows]
-                s = pnn.fuse_upsample_add(s, proj, [j - i for j, _ in lows], relu=True)
-            outs.append(s)
-        return outs
+        if self.branch_streams and len(xs) > 1:
+            # Every side stream starts behind everything queued on the main stream and the main
+            # stream resumes behind every side stream, so a tensor freed after this module is
+            # reused only by work ordered after its last reader, whichever stream made it.
+            main = torch.cuda.current_stream(self.device)
+            side = self._side_streams(len(xs) - 1)
+            ys = [None] * len(xs)
+            for i in range(len(xs) - 1, 0, -1):     # the smallest maps first: they take longest
+                side[i - 1].wait_stream(main)       # per byte and hide under branch 0
+                with torch.cuda.stream(side[i - 1]):
+                    ys[i] = self._branch(xs[i], m.branches[i])
+            ys[0] = self._branch(xs[0], m.branches[0])
+            for st in side:
+                main.wait_stream(st)
+            # the fusion rows read every branch but are independent of each other
+            outs = [None] * len(m.fuse)
+            for i in range(len(m.fuse) - 1, 0, -1):
+                if i - 1 < len(side):
+                    side[i - 1].wait_stream(main)
+                    with torch.cuda.stream(side[i - 1]):
+                        outs[i] = self._fuse_row(m, i, ys)
+            for i in range(len(m.fuse)):
+                if outs[i] is None:
+                    outs[i] = self._fuse_row(m, i, ys)
+            for st in side:
+                main.wait_stream(st)
+            return outs
+        ys = [self._branch(x, br) for x, br in zip(xs, m.branches)]
+        return [self._fuse_row(m, i, ys) for i in range(len(m.fuse))]
+
+    def _fuse_row(self, m: Module, i: int, ys: List[torch.Tensor]) -> torch.Tensor:
+        row = m.fuse[i]
+        lows = [(j, row[j]) for j in range(len(row)) if j > i]
+        s = ys[i]
+        for j in range(i):
+            t = ys[j]
+            chain = row[j]
+            for u in chain[:-1]:
+                t = self._unit(u, t)
+            # the last conv of the chain adds the running sum; it also rectifies when
+            # nothing else follows
+            s = self._unit(chain[-1], t, residual=s, relu=(j == i - 1 and not lows))
+        if lows:
+            proj = [self._unit(chain[0], ys[j]) for j, chain in lows]
+            s = pnn.fuse_upsample_add(s, proj, [j - i for j, _ in lows], relu=True)
+        return s
 
     def forward_features(self, x_s2d: torch.Tensor) -> torch.Tensor:
         sp, p = self.spec, self.p

@@ -220,3 +220,21 @@ def test_hrnet_384x288_shapes_and_determinism():
     assert a.shape == (2, 17, 96, 72)                              # 96x72 maps at 384x288
     assert torch.equal(a, net.predict(img))
     assert torch.equal(a[1:2], net.predict(img[1:2].contiguous()))
+
+
+@pytest.mark.gpu
+def test_branch_streams_give_the_single_stream_result():
+    """Branches and fusion rows of an exchange module run on streams of their own; the kernels
+    and their operands are the same, so the heat maps are bit-identical, also over repeated
+    passes (freed activations are reused across streams) and different batch sizes."""
+    net = hrnet.PoseHRNet("cuda:0")
+    net.load_state(hrnet.init_state(net.spec, seed=11))
+    assert net.branch_streams
+    imgs = [torch.from_numpy(synthetic.images_u8(b, 192, 128, seed=3 + b)).cuda() for b in (3, 1, 4)]
+    net.branch_streams = False
+    want = [net.predict(im).clone() for im in imgs]
+    net.branch_streams = True
+    for rep in range(6):
+        for im, w in zip(imgs, want):
+            assert torch.equal(net.predict(im), w)
+    assert len(net._side) == 3
