@@ -11,6 +11,7 @@ buffers, views and the one-off BN folding only.
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Tuple
 
@@ -221,6 +222,15 @@ class PoseResNet:
     def w(self, c: ConvSpec) -> torch.Tensor:
         return self.view(self.work, c.name + ".weight")
 
+    # PE_RESNET_DOWN_STREAM=0: the skip-path projections stay on the main stream (comparison)
+    down_stream = os.environ.get("PE_RESNET_DOWN_STREAM", "1") != "0"
+    _side = None
+
+    def _side_stream(self):
+        if self._side is None:
+            self._side = torch.cuda.Stream(self.device)
+        return self._side
+
     # ------------------------------------------------------------------ inference
     def _conv(self, c: ConvSpec, x, residual=None, relu=None, **kw):
         return pnn.conv2d(x, self.w(c), self.scale[c.name], self.shift[c.name], residual,
@@ -230,10 +240,21 @@ class PoseResNet:
         stem, blocks, deconvs, final = self.specs
         x = pnn.stem7x7s2(x_s2d, self.w(stem), self.scale[stem.name], self.shift[stem.name], True)
         x = pnn.maxpool3x3s2(x)
+        side = self._side_stream() if self.down_stream else None
         for b in blocks:
-            o = self._conv(b.c1, x)
-            o = self._conv(b.c2, o)
-            idn = self._conv(b.down, x) if b.down else x
+            if b.down and side is not None:
+                # the projection of the skip path runs beside conv1 / conv2 (it is bound by
+                # memory traffic, conv2 by the matrix cores); both streams wait for each other,
+                # so freed activations are reused only behind their last reader
+                main = torch.cuda.current_stream(self.device)
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    idn = self._conv(b.down, x)
+                o = self._conv(b.c2, self._conv(b.c1, x))
+                main.wait_stream(side)
+            else:
+                o = self._conv(b.c2, self._conv(b.c1, x))
+                idn = self._conv(b.down, x) if b.down else x
             x = self._conv(b.c3, o, residual=idn, relu=True)
         for d in deconvs:
             x = pnn.deconv4x4s2(x, self.w(d), self.scale[d.name], self.shift[d.name], True)
