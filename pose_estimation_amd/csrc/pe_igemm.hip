@@ -128,7 +128,7 @@ __attribute__((amdgpu_waves_per_eu(MINB * WM / 2, MINB * WM / 2))) void igemm_ke
             pixbase[i] = 0;
         }
     }
-    const int kc = p.Cin / BK;   // K steps per tap
+    const int kc = (p.Cin + BK - 1) / BK;   // K steps per tap; the last may be part-filled
     const int KT = T * kc;       // K steps in total
     const long ktot = p.wk_row;  // weight row length
     const uint16_t* zero = reinterpret_cast<const uint16_t*>(g_zero16);
@@ -153,6 +153,7 @@ __attribute__((amdgpu_waves_per_eu(MINB * WM / 2, MINB * WM / 2))) void igemm_ke
         const int dy = (int)(int8_t)(info & 0xff);
         const int dx = (int)(int8_t)((info >> 8) & 0xff);
         const int coff = cstep * BK + cc * 8;
+        const bool kin = coff < p.Cin;  // Cin % 8 == 0: a 16-byte chunk is whole or absent
         const long wk = (long)(info >> 16) * p.Cin + coff;  // K offset in a weight row
         const int xextra = coff >> p.cshift;
         const int ch = coff & p.cmask;
@@ -160,7 +161,7 @@ __attribute__((amdgpu_waves_per_eu(MINB * WM / 2, MINB * WM / 2))) void igemm_ke
         for (int i = 0; i < XI; ++i) {
             const int iy = iy0[i] + dy;
             const int ix = ix0[i] + dx + xextra;
-            const bool ok = (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
+            const bool ok = kin && (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
             const long off = (long)(pixbase[i] + iy * p.Wi + ix) * p.Cx + ch;
             const uint16_t* src = ok ? p.x + off : zero;
             __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(dst + (RPI * i + 8 * wid) * ROWB),
@@ -169,7 +170,7 @@ __attribute__((amdgpu_waves_per_eu(MINB * WM / 2, MINB * WM / 2))) void igemm_ke
 #pragma unroll
         for (int i = 0; i < WI; ++i) {
             const int n = n0 + r0 + RPI * i;
-            const uint16_t* src = (n < p.N) ? wbase + ((long)n * ktot + wk) : zero;
+            const uint16_t* src = (kin && n < p.N) ? wbase + ((long)n * ktot + wk) : zero;
             __builtin_amdgcn_global_load_lds(
                 (gptr_t)src, (lptr_t)(dst + XBYTES + (RPI * i + 8 * wid) * ROWB), 16, 0, 0);
         }
@@ -553,8 +554,12 @@ int32_t igemm_launch(const IgemmParams& pin, hipStream_t st, const char* what) {
     PE_REQUIRE(p.x && p.w && p.y, PE_E_INVALID, "%s: NULL tensor pointer", what);
     PE_REQUIRE(p.B > 0 && p.Hi > 0 && p.Wi > 0 && p.N > 0 && p.nphase <= kMaxPhases, PE_E_INVALID,
                "%s: sizes must be positive", what);
-    PE_REQUIRE(p.Cin > 0 && p.Cin % BK == 0, PE_E_UNSUPPORTED,
-               "%s: K per tap (%d) must be a multiple of %d", what, p.Cin, BK);
+    // a tap's K run is walked in steps of 64; a last step that is only part-filled loads the
+    // zero block for the chunks past the run (weights and activations alike)
+    PE_REQUIRE(p.Cin > 0 && p.Cin % 8 == 0, PE_E_UNSUPPORTED,
+               "%s: K per tap (%d) must be a multiple of 8", what, p.Cin);
+    PE_REQUIRE(p.cshift == 31 || p.Cin == BK, PE_E_INVALID,
+               "%s: K runs that span pixels are %d long", what, BK);
     PE_REQUIRE(p.Cx % 8 == 0, PE_E_UNSUPPORTED, "%s: channels per pixel (%d) must be a multiple of 8",
                what, p.Cx);
     PE_REQUIRE(aligned(p.x, 16) && aligned(p.w, 16) && aligned(p.y, 16) && aligned(p.res, 16) &&

@@ -10,10 +10,13 @@ linear 1x1 projections.  Once the running stride reaches `output_stride` (8) lat
 become dilation, so the feature map stays 40x40 at 320x320.  Heads: a 1x1 conv to K heat maps
 and, optionally, a 1x1 conv to 4 channels per keypoint pair (vector maps); float32 NCHW outputs.
 
-Layout: activations NHWC bf16 with every channel count padded up to a multiple of 64 (the
-implicit-GEMM K step); padded weights, scales and shifts are zero, so padded channels stay zero
-through ReLU6 and the linear projections.  The pointwise convs run on the MFMA engine
-(pe_conv2d_fwd_bf16), the depthwise convs on the bandwidth-bound pe_depthwise3x3_fwd_bf16.
+Layout: activations NHWC bf16 at their true channel counts (multiples of 8; a count that is
+not would be padded up with zero weights, scales and shifts, so the padding stays zero through
+ReLU6 and the linear projections).  The pointwise convs run on the MFMA engine
+(pe_conv2d_fwd_bf16), which walks a K run of 24, 96, 144 ... channels in steps of 64 with a
+part-filled last step, or packs 16 / 32 channels as multi-pixel runs; the depthwise convs run on
+the bandwidth-bound pe_depthwise3x3_fwd_bf16.  Nothing is padded to the GEMM's K step in
+memory: these networks are bound by tensor traffic, not by the matrix cores.
 """
 from __future__ import annotations
 
@@ -32,8 +35,10 @@ MBV2_SETTING = [(1, 16, 1, 1), (6, 24, 2, 2), (6, 32, 3, 2), (6, 64, 4, 2), (6, 
                 (6, 160, 3, 2), (6, 320, 1, 1)]
 
 
-def pad64(c: int) -> int:
-    return (c + 63) // 64 * 64
+def pad8(c: int) -> int:
+    """Channel counts are kept as they are, rounded up to whole 16-byte chunks (every count of
+    the public MobileNetV2 definition is a multiple of 8 already)."""
+    return (c + 7) // 8 * 8
 
 
 @dataclass
@@ -162,6 +167,7 @@ class PoseMobileNetV2:
         self.blocks = mobilenet_v2_specs(output_stride, setting)
         self.output_stride = output_stride
         self.p: Dict[str, torch.Tensor] = {}
+        self.kw: Dict[str, dict] = {}
 
     # ------------------------------------------------------------------ parameters
     def _fold(self, st, name, cout_pad):
@@ -175,27 +181,33 @@ class PoseMobileNetV2:
         self.p[name + ".shift"] = shp.to(self.device)
 
     def _pointwise(self, st, name, cin, cout, fold=True):
-        w = torch.zeros(pad64(cout) if fold else cout, 1, 1, pad64(cin))
-        w[:cout, 0, 0, :cin] = st[name + ".weight"][:, :, 0, 0]
-        self.p[name + ".weight"] = w.to(BF16).to(self.device)
+        w = torch.zeros(pad8(cout) if fold else cout, pad8(cin), 1, 1)
+        w[:cout, :cin] = st[name + ".weight"]
+        if pad8(cin) in (8, 16, 32):      # multi-pixel K runs: the engine's narrow packing
+            self.p[name + ".weight"] = pnn.pack_conv_weight_narrow(w).to(self.device)
+            self.kw[name] = {"kw": 1}
+        else:
+            self.p[name + ".weight"] = pnn.pack_conv_weight(w).to(self.device)
+            self.kw[name] = {}
         if fold:
-            self._fold(st, name, pad64(cout))
+            self._fold(st, name, pad8(cout))
         else:
             self.p[name + ".bias"] = st[name + ".bias"].float().to(self.device)
 
     def load_state(self, st: Dict[str, torch.Tensor]) -> None:
         self.p.clear()
-        self.p["stem.weight"] = torch.zeros(64, 2, 64, dtype=BF16)
+        sc = pad8(st["stem.weight"].shape[0])
+        self.p["stem.weight"] = torch.zeros(sc, 2, 64, dtype=BF16)
         self.p["stem.weight"][:st["stem.weight"].shape[0]] = pnn.pack_stem3x3_weight(st["stem.weight"])
         self.p["stem.weight"] = self.p["stem.weight"].to(self.device)
-        self._fold(st, "stem", 64)
+        self._fold(st, "stem", sc)
         for b in self.blocks:
             if b.expand != 1:
                 self._pointwise(st, b.name + ".expand", b.cin, b.mid)
-            w = torch.zeros(9, pad64(b.mid))
+            w = torch.zeros(9, pad8(b.mid))
             w[:, :b.mid] = st[b.name + ".dw.weight"][:, 0].reshape(b.mid, 9).t()
             self.p[b.name + ".dw.weight"] = w.to(BF16).contiguous().to(self.device)
-            self._fold(st, b.name + ".dw", pad64(b.mid))
+            self._fold(st, b.name + ".dw", pad8(b.mid))
             self._pointwise(st, b.name + ".project", b.mid, b.cout)
         cf = self.blocks[-1].cout
         self._pointwise(st, "heat", cf, self.num_joints, fold=False)
@@ -210,13 +222,14 @@ class PoseMobileNetV2:
             h = x
             if b.expand != 1:
                 n = b.name + ".expand"
-                h = pnn.conv2d(h, p[n + ".weight"], p[n + ".scale"], p[n + ".shift"], relu=2)
+                h = pnn.conv2d(h, p[n + ".weight"], p[n + ".scale"], p[n + ".shift"], relu=2,
+                               **self.kw[n])
             n = b.name + ".dw"
             h = pnn.depthwise3x3(h, p[n + ".weight"], p[n + ".scale"], p[n + ".shift"],
                                  stride=b.stride, dilation=b.dilation, relu=2)
             n = b.name + ".project"
             x = pnn.conv2d(h, p[n + ".weight"], p[n + ".scale"], p[n + ".shift"],
-                           residual=x if b.residual else None, relu=0)
+                           residual=x if b.residual else None, relu=0, **self.kw[n])
         return x
 
     def predict(self, images_u8: torch.Tensor):
@@ -225,10 +238,12 @@ class PoseMobileNetV2:
         if not self.p:
             raise RuntimeError("load_state() has not been called")
         f = self.forward_features(pnn.preprocess_u8(images_u8))
-        heat = pnn.conv2d(f, self.p["heat.weight"], None, self.p["heat.bias"], out_f32_nchw=True)
+        heat = pnn.conv2d(f, self.p["heat.weight"], None, self.p["heat.bias"], out_f32_nchw=True,
+                          **self.kw["heat"])
         if not self.num_pairs:
             return heat
-        vec = pnn.conv2d(f, self.p["vec.weight"], None, self.p["vec.bias"], out_f32_nchw=True)
+        vec = pnn.conv2d(f, self.p["vec.weight"], None, self.p["vec.bias"], out_f32_nchw=True,
+                         **self.kw["vec"])
         return heat, vec
 
     def decode(self, heatmaps: torch.Tensor):
@@ -247,25 +262,25 @@ COCO_PAIRS = [(15, 13), (13, 11), (16, 14), (14, 12), (11, 12), (5, 11), (6, 12)
 def _block_layers(b: MBBlock) -> List[Layer]:
     layers = []
     if b.expand != 1:
-        layers.append(Layer(b.name + ".expand", "conv", pad64(b.cin), pad64(b.mid), 1, 1, 2))
-    layers.append(Layer(b.name + ".dw", "dw", pad64(b.mid), pad64(b.mid), 3, b.stride, 2,
+        layers.append(Layer(b.name + ".expand", "conv", pad8(b.cin), pad8(b.mid), 1, 1, 2))
+    layers.append(Layer(b.name + ".dw", "dw", pad8(b.mid), pad8(b.mid), 3, b.stride, 2,
                         b.dilation))
-    layers.append(Layer(b.name + ".project", "conv", pad64(b.mid), pad64(b.cout), 1, 1, 0))
+    layers.append(Layer(b.name + ".project", "conv", pad8(b.mid), pad8(b.cout), 1, 1, 0))
     return layers
 
 
 def _graph_layers(blocks: List[MBBlock], num_joints: int, num_pairs: int, stem_ch: int = 32,
                   det_blocks: Optional[List[MBBlock]] = None, anchors_per_cell: int = 3):
-    layers = [Layer("stem", "stem3", 3, pad64(stem_ch), 3, 2, 2)]
+    layers = [Layer("stem", "stem3", 3, pad8(stem_ch), 3, 2, 2)]
     for b in blocks:
         layers.extend(_block_layers(b))
-    cf = pad64(blocks[-1].cout)
+    cf = pad8(blocks[-1].cout)
     layers.append(Layer("heat", "head", cf, num_joints))
     if num_pairs:
         layers.append(Layer("vec", "head", cf, 4 * num_pairs))
     for i, b in enumerate(det_blocks or []):     # forward execution order: level by level
         layers.extend(_block_layers(b))
-        layers.append(Layer(f"box{i + 1}", "head", pad64(b.cout), anchors_per_cell * BOX_FIELDS))
+        layers.append(Layer(f"box{i + 1}", "head", pad8(b.cout), anchors_per_cell * BOX_FIELDS))
     return layers
 
 

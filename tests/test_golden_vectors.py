@@ -253,9 +253,9 @@ def test_hip_mobilenet_blocks_match_golden(gv):
     net.load_state(mstate)
     for (b0, x, dout), b in zip(cases, [net.blocks[i] for i in mg.MB_BLOCKS]):
         assert b.name == b0.name
-        xp = torch.zeros(*x.shape[:3], mb.pad64(b.cin))
+        xp = torch.zeros(*x.shape[:3], mb.pad8(b.cin))
         xp[..., :b.cin] = x
-        dp = torch.zeros(*dout.shape[:3], mb.pad64(b.cout))
+        dp = torch.zeros(*dout.shape[:3], mb.pad8(b.cout))
         dp[..., :b.cout] = dout
         net.grads.zero_()
         net.begin(True)

@@ -57,6 +57,11 @@ BWD_CASES = [
     (2, 16, 12, 256, 512, 1, 2, 0),
     (1, 8, 6, 512, 256, 3, 1, 1),
     (2, 10, 14, 64, 192, 3, 2, 1),
+    (2, 16, 12, 96, 24, 1, 1, 0),      # channel counts that are multiples of 8, not of 64
+    (2, 16, 12, 24, 144, 1, 1, 0),
+    (3, 10, 10, 160, 960, 1, 1, 0),
+    (2, 9, 7, 96, 40, 3, 1, 1),
+    (2, 12, 10, 144, 72, 3, 2, 1),
 ]
 
 

@@ -47,6 +47,11 @@ CONV_CASES = [
     (5, 7, 5, 64, 192, 3, 1, 1),      # odd sizes, partial tiles in M and N
     (1, 64, 48, 64, 68, 3, 1, 1),     # N not a multiple of 16
     (2, 9, 11, 128, 36, 3, 2, 1),     # odd H, W with stride 2; N < 64
+    (2, 16, 12, 96, 24, 1, 1, 0),     # K per tap not a multiple of 64: part-filled last K step
+    (2, 16, 12, 24, 144, 1, 1, 0),    # a single, part-filled K step
+    (3, 10, 10, 160, 960, 1, 1, 0),
+    (2, 9, 7, 96, 40, 3, 1, 1),       # ... and with more than one tap
+    (2, 12, 10, 144, 64, 3, 2, 1),
 ]
 
 

@@ -82,7 +82,7 @@ def test_single_blocks_against_autograd():
     g = torch.Generator().manual_seed(5)
     B, H, W = 3, 16, 12
     for b in net.blocks:
-        cin_p = mb.pad64(b.cin)
+        cin_p = mb.pad8(b.cin)
         x = torch.zeros(B, H, W, cin_p)
         x[..., :b.cin] = to.bf16r(torch.randn((B, H, W, b.cin), generator=g))
         net.grads.zero_()
@@ -90,7 +90,7 @@ def test_single_blocks_against_autograd():
         xv = Var(x.to(torch.bfloat16).cuda(), True)
         out = net.block(b, xv)
         Ho, Wo = out.t.shape[1:3]
-        dout = torch.zeros(B, Ho, Wo, mb.pad64(b.cout))
+        dout = torch.zeros(B, Ho, Wo, mb.pad8(b.cout))
         dout[..., :b.cout] = to.bf16r(torch.randn((B, Ho, Wo, b.cout), generator=g))
         out.grad = dout.to(torch.bfloat16).cuda()
         net.backward({})
