@@ -202,7 +202,9 @@ int32_t pe_sgd_step(float* p, float* mom, const float* grad, uint16_t* p_bf16,
  *             kh = (py ? 2 - 2a : 1 + 2a) ... see pe_pack layout in ops.py)
  * Accumulation is fp32.  Epilogue: y = acc*scale[c] + shift[c] (+ residual)
  * (-> ReLU) -> bf16; scale/shift/residual may be NULL.
- * Cin must be a multiple of 64, Cout a multiple of 4 (except f32-NCHW output).
+ * Cin must be a multiple of 8 (a tap's run is walked in steps of 64; the part of the last
+ * step past the run reads zeros, nothing is padded in memory; the transposed conv needs a
+ * multiple of 64), Cout a multiple of 4 (except f32-NCHW output).
  * Narrow inputs (pe_conv2d_fwd_bf16 only): Cin of 8, 16 or 32 is accepted with weights
  * packed [Cout][KH][ceil(KW/P)][P*Cin], P = 64/Cin: run c of a filter row holds taps
  * kw = c*P .. c*P+P-1 pixel by pixel (zero where kw >= KW), because P horizontally
