@@ -69,17 +69,32 @@ def test_hrnet_graph_layers_follow_execution_order():
 
 
 def test_mobilenet_channel_padding():
+    """Channel counts stay as the architecture gives them (all multiples of 8 in MobileNetV2-1.0);
+    only a count that is not a whole number of 16-byte chunks is padded, with zero weights and
+    switched-off norms."""
     blocks = mb.mobilenet_v2_specs()
     layers = mb._graph_layers(blocks, 17, 19)
-    assert all(L.cout % 64 == 0 for L in layers if L.kind != "head")
+    by = {L.name: L for L in layers}
+    assert (by["block1.expand"].cin, by["block1.expand"].cout) == (16, 96)
+    assert (by["block1.project"].cin, by["block1.project"].cout) == (96, 24)
+    assert by["block16.project"].cout == 320 and by["stem"].cout == 32
+    assert by["block1.expand"].narrow and not by["block2.expand"].narrow     # 16 vs 24 channels
     assert [L.name for L in layers[-2:]] == ["heat", "vec"] and layers[-1].cout == 76
     st = mb.init_state(blocks, 17, 19, seed=3)
     ps = mb.pad_state(layers, st)
+    assert all(torch.equal(ps[k], st[k]) for k in st if k.endswith(".weight"))
+    # a width that needs padding: 12 -> 16 and 20 -> 24 channels
+    blocks = mb.mobilenet_v2_specs(8, [(1, 12, 1, 1), (6, 20, 1, 2)])
+    layers = mb._graph_layers(blocks, 17, 0)
+    assert all(L.cout % 8 == 0 and L.cin % 8 == 0 for L in layers if L.kind not in ("head", "stem3"))
+    st = mb.init_state(blocks, 17, 0, seed=3)
+    ps = mb.pad_state(layers, st)
     w, wp = st["block1.project.weight"], ps["block1.project.weight"]
-    assert tuple(wp.shape) == (64, 128, 1, 1)
-    assert torch.equal(wp[:24, :96], w) and not wp[24:].any() and not wp[:, 96:].any()
-    assert ps["block1.project.bn.gamma"][24:].abs().sum() == 0     # padded norms are switched off
-    assert torch.equal(ps["block1.dw.weight"][:96], st["block1.dw.weight"])
+    assert tuple(w.shape) == (20, 72, 1, 1) and tuple(wp.shape) == (24, 72, 1, 1)
+    assert torch.equal(wp[:20], w) and not wp[20:].any()
+    assert ps["block1.project.bn.gamma"][20:].abs().sum() == 0     # padded norms are switched off
+    w, wp = st["block1.expand.weight"], ps["block1.expand.weight"]
+    assert tuple(wp.shape) == (72, 16, 1, 1) and torch.equal(wp[:, :12], w) and not wp[:, 12:].any()
     with pytest.raises(KeyError):
         mb.pad_state(layers, {})
 
