@@ -57,6 +57,7 @@ class TrainablePoseResNet(PoseResNet):
         self.layer_starts: List[int] = [self.offsets[c.name + ".weight"][0] for c in self.convs]
         self.bucketer: Optional[GradBucketer] = None
         self.saved: dict = {}
+        self._wt_pending = False
         # backward-data GEMMs mask their result and reduce it for the batch norm below them
         # (PE_FUSE_BN_BWD=0: the separate reduction pass, for comparison)
         self.fuse_bn_bwd = os.environ.get("PE_FUSE_BN_BWD", "1") != "0"
@@ -84,8 +85,16 @@ class TrainablePoseResNet(PoseResNet):
         self.work.copy_(self.master)
         self.refresh_transposes()
 
+    def _join_transposes(self) -> None:
+        """The re-pack a training step left running on the side stream is done before anything
+        on the current stream touches the backward-data weights."""
+        if self._wt_pending:
+            torch.cuda.current_stream(self.device).wait_stream(self.wgrad_stream)
+            self._wt_pending = False
+
     def refresh_transposes(self) -> None:
         """Re-packs every weight for the backward-data GEMMs (one launch for all layers)."""
+        self._join_transposes()
         if self._tplan is None:
             plan = pnn.TransposePlan(self.work.device)
             for c in self.convs:
@@ -99,6 +108,12 @@ class TrainablePoseResNet(PoseResNet):
                     plan.add(w.view(c.cout, 1, c.cin), self.wt[c.name])
             self._tplan = plan
         self._tplan.run()
+
+    def _tplan_run(self) -> None:
+        if self._tplan is None:
+            self.refresh_transposes()
+        else:
+            self._tplan.run()
 
     def _workspace(self, z: torch.Tensor) -> torch.Tensor:
         C = z.shape[3]
@@ -152,6 +167,7 @@ class TrainablePoseResNet(PoseResNet):
     def block_backward(self, b, s: dict, dout: torch.Tensor) -> torch.Tensor:
         """Backward of block_forward: accumulates the block's parameter gradients into the
         gradient arena and returns the gradient with respect to the block input."""
+        self._join_transposes()
         x = s["x"]
         hw_in = tuple(x.shape[1:3])
         hw_mid = tuple(s["a1"].shape[1:3])
@@ -194,6 +210,7 @@ class TrainablePoseResNet(PoseResNet):
         return dict(x=x, z=z, a=self._bn(d, z, rows))
 
     def deconv_backward(self, d, s: dict, da: torch.Tensor) -> torch.Tensor:
+        self._join_transposes()
         dz, _ = self._bn_bwd(d, da, s["a"], s["z"], rebuild=True)
         with self._beside(s["x"], dz):
             pnn.deconv4x4s2_bwd_weight(s["x"], dz, self._g(d.name + ".weight"))
@@ -283,6 +300,7 @@ class TrainablePoseResNet(PoseResNet):
         """grad_hm: float32 [B,K,H,W] = dLoss/dHeatmaps.  Fills self.grads (pre-zeroed here)."""
         stem, blocks, deconvs, final = self.specs
         sv = self.saved
+        self._join_transposes()
         self.grads.zero_()
         # final 1x1 conv + bias
         dyp = pnn.final_grad_prepare(grad_hm, FINAL_KPAD, self._g(final.name + ".bias"))
@@ -352,6 +370,16 @@ class TrainablePoseResNet(PoseResNet):
                          grad_scale=scale)
         else:
             raise ValueError(f"unknown optimizer {optimizer!r}")
-        self.refresh_transposes()
+        # the backward-data weights are not needed before the next backward pass: their re-pack
+        # runs on the side stream, beside the next step's forward pass
+        side = self.wgrad_stream if os.environ.get("PE_TRANSPOSE_SIDE", "1") != "0" else None
+        if side is not None:
+            self._join_transposes()
+            side.wait_stream(torch.cuda.current_stream(self.device))
+            with torch.cuda.stream(side):
+                self._tplan_run()
+            self._wt_pending = True
+        else:
+            self.refresh_transposes()
         self.saved = {}
         return loss, per_joint
