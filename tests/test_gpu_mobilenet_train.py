@@ -78,7 +78,20 @@ def check_grads(net, rg, bound, fg=None):
 
 
 def test_single_blocks_against_autograd():
-    net, state = make_net(seed=21)
+    _single_blocks(*make_net(seed=21))
+
+
+def test_single_blocks_with_padded_channel_counts():
+    """Widths that are not whole 16-byte chunks (12, 20, 36 channels and their expansions) are
+    padded to the next multiple of 8 with zero weights and switched-off norms: the padding holds
+    exact zeros in every activation and gradient, and the true part matches autograd."""
+    net, state = make_net(seed=23, setting=[(1, 12, 1, 1), (6, 20, 2, 2), (6, 36, 1, 1)])
+    assert [(b.cin, b.mid, b.cout) for b in net.blocks][-1] == (20, 120, 36)
+    assert net.by_name["block3.project"].cout == 40 and net.by_name["block1.expand"].cin == 16
+    _single_blocks(net, state)
+
+
+def _single_blocks(net, state):
     g = torch.Generator().manual_seed(5)
     B, H, W = 3, 16, 12
     for b in net.blocks:
