@@ -360,17 +360,36 @@ class TrainablePoseHRNet(TrainGraph):
         self.sigma = sigma
         self.radius = int(round(3 * sigma))
         self.heatmap_stride = heatmap_stride
+        self._side: List[torch.cuda.Stream] = []
+        self.branch_streams = os.environ.get("PE_HRNET_BRANCH_STREAMS", "1") != "0"
 
     def _u(self, u: Unit, x, residual=None, relu=None):
         return self.unit(self.by_name[u.name], x, residual,
                          None if relu is None else (1 if relu else 0))
 
+    def _branch(self, x, br):
+        for blk in br:
+            x = self._u(blk.c2, self._u(blk.c1, x), residual=x, relu=True)
+        return x
+
     def _module(self, m: Module, xs):
-        ys = []
-        for x, br in zip(xs, m.branches):
-            for blk in br:
-                x = self._u(blk.c2, self._u(blk.c1, x), residual=x, relu=True)
-            ys.append(x)
+        if not self.training and self.branch_streams and len(xs) > 1:
+            # inference: the branches on streams of their own, as in PoseHRNet._module (training
+            # is bound by the host's launch rate, where concurrency on the GPU buys nothing)
+            main = torch.cuda.current_stream(self.device)
+            while len(self._side) < len(xs) - 1:
+                self._side.append(torch.cuda.Stream(self.device))
+            side = self._side[:len(xs) - 1]
+            ys = [None] * len(xs)
+            for i in range(len(xs) - 1, 0, -1):
+                side[i - 1].wait_stream(main)
+                with torch.cuda.stream(side[i - 1]):
+                    ys[i] = self._branch(xs[i], m.branches[i])
+            ys[0] = self._branch(xs[0], m.branches[0])
+            for st in side:
+                main.wait_stream(st)
+        else:
+            ys = [self._branch(x, br) for x, br in zip(xs, m.branches)]
         outs = []
         for i, row in enumerate(m.fuse):
             lows = [(j, row[j]) for j in range(len(row)) if j > i]
