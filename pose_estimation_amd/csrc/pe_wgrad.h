@@ -11,6 +11,11 @@ namespace pe {
 // dW slab in the workspace and an ordered reduction folds them (bit-stable, no float atomics).
 // Two workgroups per CU measured best on the training step (256: 14.2 ms, 512: 13.2, 1024: 13.3).
 constexpr long kWgradTargetBlocks = 512;
+// Weights with at least this many 128 x 128 output tiles aim for half as many workgroups: every
+// split costs a slab of the weight's size.  Measured per step (tiles >= 8 vs never): ResNet-50
+// 9.07 vs 9.26 ms, HRNet-style 37.7 vs 38.5 ms, MobileNetV2 16.44 vs 16.53 ms; with a threshold
+// of 4 the HRNet step loses what it gained (38.6 ms).
+constexpr long kWgradBigTiles = 8;
 constexpr long kWgradMaxBlocks = 2048;   // upper bound the workspace is sized for
 
 struct WgradParams {

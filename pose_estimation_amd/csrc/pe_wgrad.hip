@@ -269,7 +269,11 @@ int32_t wgrad_launch(WgradParams& p, void* workspace, size_t workspace_bytes, hi
     const long P = (long)p.Nw * ktot;
     const long tiles = ((p.N + 127) / 128) * ((ktot + 127) / 128);
     static const char* tune = getenv("PE_WGRAD_BLOCKS");  // tuning aid, at most kWgradMaxBlocks
-    long target = tune ? atol(tune) : kWgradTargetBlocks;
+    static const char* tune_t = getenv("PE_WGRAD_BIG_TILES");  // tuning aid
+    const long big_tiles = tune_t ? atol(tune_t) : kWgradBigTiles;
+    // a weight with many output tiles fills the chip with fewer pixel splits, and every split
+    // costs a slab of the weight's size to write and fold
+    long target = tune ? atol(tune) : (tiles >= big_tiles ? kWgradTargetBlocks / 2 : kWgradTargetBlocks);
     if (target < 1 || target > kWgradMaxBlocks) target = kWgradTargetBlocks;
     long splits = (target + tiles - 1) / tiles;
     const long max_splits = (M + 255) / 256;
