@@ -190,7 +190,7 @@ __global__ __launch_bounds__(256) void add_bf16_kernel(const uint4* __restrict__
 
 static unsigned stream_grid(long n) {
     long b = (n + 255) / 256;
-    if (b > 256 * 16) b = 256 * 16;
+    if (b > 256 * 128) b = 256 * 128;
     return (unsigned)(b < 1 ? 1 : b);
 }
 

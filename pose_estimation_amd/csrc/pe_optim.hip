@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, float* 
 static unsigned optim_grid(long n) {
     long blocks = ((n >> 2) + 255) / 256;
     if (blocks < 1) blocks = 1;
-    if (blocks > 256 * 16) blocks = 256 * 16;
+    if (blocks > 256 * 128) blocks = 256 * 128;
     return (unsigned)blocks;
 }
 
