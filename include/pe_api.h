@@ -162,6 +162,27 @@ int32_t pe_mse_fwd_bwd(const void* pred, int32_t pred_dtype,
                        float* loss, float* per_joint, void* grad,
                        void* workspace, pe_stream_t stream);
 
+/* pe_mse_fwd_bwd without the workspace argument and without any allocation.
+ * No counterpart in the reference: it is for callers that cannot allocate or
+ * size device memory around a call (code under HIP graph capture, tight serving
+ * loops, harnesses that forbid hipMalloc).  Same arguments, same results bit for
+ * bit; the per-map partial sums go to a device array inside the library
+ * (PE_MSE_STATIC_MAX_MAPS floats = 256 KB, one copy per GPU, held until the
+ * process ends).  B*K > PE_MSE_STATIC_MAX_MAPS returns PE_E_UNSUPPORTED.  The
+ * call uses the scratch of the CURRENT device, so `stream` must belong to it.
+ * All calls on one GPU share that array: two calls that overlap on one GPU
+ * (different streams, or threads) race; calls on one stream are ordered.  The
+ * first call on a device looks up the array's address (hipGetSymbolAddress,
+ * not an allocation); make that first call outside a graph capture. */
+#define PE_MSE_STATIC_MAX_MAPS 65536
+int32_t pe_mse_fwd_bwd_static(const void* pred, int32_t pred_dtype,
+                              const float* target, const float* joints,
+                              float* weight, const uint8_t* mask,
+                              int32_t B, int32_t K, int32_t H, int32_t W,
+                              float stride, float sigma, int32_t radius,
+                              float* loss, float* per_joint, void* grad,
+                              pe_stream_t stream);
+
 /* ------------------------------------------------------------------------
  * a6. Optimizer steps over a flat float32 parameter arena.
  * Replaces: the optimizer of train.py / model/base_model.py

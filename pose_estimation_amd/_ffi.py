@@ -18,6 +18,7 @@ PE_E_UNSUPPORTED = -3
 PE_DTYPE_F32 = 0
 PE_DTYPE_BF16 = 1
 PE_MAX_RADIUS = 31
+PE_MSE_STATIC_MAX_MAPS = 65536
 
 
 class PeError(RuntimeError):
@@ -62,6 +63,12 @@ SIGNATURES = {
         [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p,
          c_int32, c_int32, c_int32, c_int32, c_float, c_float, c_int32,
          c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
+    ),
+    "pe_mse_fwd_bwd_static": (
+        c_int32,
+        [c_void_p, c_int32, c_void_p, c_void_p, c_void_p, c_void_p,
+         c_int32, c_int32, c_int32, c_int32, c_float, c_float, c_int32,
+         c_void_p, c_void_p, c_void_p, c_void_p],
     ),
     "pe_adam_step": (
         c_int32,

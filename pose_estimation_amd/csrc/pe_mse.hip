@@ -7,6 +7,8 @@
 // bit-stable from run to run (no float atomics).
 #include <math.h>
 
+#include <mutex>
+
 #include "pe_common.h"
 #include "pe_render_device.h"
 
@@ -198,17 +200,20 @@ extern "C" size_t pe_mse_workspace_bytes(int32_t B, int32_t K) {
     return (((size_t)B * (size_t)K * sizeof(float)) + 15) & ~(size_t)15;
 }
 
-extern "C" int32_t pe_mse_fwd_bwd(const void* pred, int32_t pred_dtype, const float* target,
-                                  const float* joints, float* weight, const uint8_t* mask,
-                                  int32_t B, int32_t K, int32_t H, int32_t W, float stride,
-                                  float sigma, int32_t radius, float* loss, float* per_joint,
-                                  void* grad, void* workspace, pe_stream_t stream) {
-    using namespace pe;
+namespace pe {
+
+// Validation and the two launches shared by pe_mse_fwd_bwd and pe_mse_fwd_bwd_static; `partial`
+// is the per-map scratch (B*K floats of device memory), whoever owns it.
+static int32_t mse_run(const void* pred, int32_t pred_dtype, const float* target,
+                       const float* joints, float* weight, const uint8_t* mask, int32_t B,
+                       int32_t K, int32_t H, int32_t W, float stride, float sigma, int32_t radius,
+                       float* loss, float* per_joint, void* grad, float* partial,
+                       pe_stream_t stream) {
     PE_REQUIRE(B > 0 && K > 0 && H > 0 && W > 0, PE_E_INVALID,
                "pe_mse_fwd_bwd: B, K, H, W must be positive");
     PE_REQUIRE(pred_dtype == PE_DTYPE_F32 || pred_dtype == PE_DTYPE_BF16, PE_E_INVALID,
                "pe_mse_fwd_bwd: unknown pred_dtype %d", pred_dtype);
-    PE_REQUIRE(pred && loss && workspace, PE_E_INVALID,
+    PE_REQUIRE(pred && loss && partial, PE_E_INVALID,
                "pe_mse_fwd_bwd: pred, loss and workspace must be non-NULL");
     PE_REQUIRE((target != nullptr) != (joints != nullptr), PE_E_INVALID,
                "pe_mse_fwd_bwd: exactly one of target and joints must be given");
@@ -244,7 +249,7 @@ extern "C" int32_t pe_mse_fwd_bwd(const void* pred, int32_t pred_dtype, const fl
     a.weight_out = fused ? weight : nullptr;
     a.mask = mask;
     a.grad = grad;
-    a.partial = static_cast<float*>(workspace);
+    a.partial = partial;
     a.nmaps = (int)nmaps;
     a.K = K;
     a.H = H;
@@ -269,4 +274,71 @@ extern "C" int32_t pe_mse_fwd_bwd(const void* pred, int32_t pred_dtype, const fl
     const float loss_scale = (float)(0.5 / n);
     return launch_map_sum_reduce(a.partial, B, K, joint_scale, loss_scale, per_joint, loss, st,
                                  "pe_mse_fwd_bwd(stage 2)");
+}
+
+}  // namespace pe
+
+extern "C" int32_t pe_mse_fwd_bwd(const void* pred, int32_t pred_dtype, const float* target,
+                                  const float* joints, float* weight, const uint8_t* mask,
+                                  int32_t B, int32_t K, int32_t H, int32_t W, float stride,
+                                  float sigma, int32_t radius, float* loss, float* per_joint,
+                                  void* grad, void* workspace, pe_stream_t stream) {
+    return pe::mse_run(pred, pred_dtype, target, joints, weight, mask, B, K, H, W, stride, sigma,
+                       radius, loss, per_joint, grad, static_cast<float*>(workspace), stream);
+}
+
+// ---- The allocation-free variant ---------------------------------------------------------
+// The per-map partial sums live in a file-scope device array instead of a caller workspace.
+// Every GPU the library runs on holds its own copy (256 KB) at its own address until the
+// process ends.  In host code the array's NAME is only a stand-in for that memory: the device
+// address comes from hipGetSymbolAddress, once per device with that device current, and only
+// that pointer is ever handed to a kernel.
+static __device__ __align__(256) float scratch[PE_MSE_STATIC_MAX_MAPS];
+
+namespace pe {
+
+constexpr int kMaxDevices = 64;
+static std::mutex g_scratch_mutex;
+static float* g_scratch_ptr[kMaxDevices];  // device address of `scratch`, per device ordinal
+
+static int32_t static_scratch(float** out) {
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    PE_REQUIRE(e == hipSuccess, PE_E_HIP, "pe_mse_fwd_bwd_static: hipGetDevice: %s",
+               hipGetErrorString(e));
+    PE_REQUIRE(dev >= 0 && dev < kMaxDevices, PE_E_UNSUPPORTED,
+               "pe_mse_fwd_bwd_static: device ordinal %d outside [0, %d)", dev, kMaxDevices);
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (g_scratch_ptr[dev] == nullptr) {
+        float* ptr = nullptr;
+        e = hipGetSymbolAddress(reinterpret_cast<void**>(&ptr), HIP_SYMBOL(scratch));
+        PE_REQUIRE(e == hipSuccess && ptr != nullptr, PE_E_HIP,
+                   "pe_mse_fwd_bwd_static: hipGetSymbolAddress(scratch) on device %d: %s", dev,
+                   hipGetErrorString(e));
+        g_scratch_ptr[dev] = ptr;
+    }
+    *out = g_scratch_ptr[dev];
+    return PE_OK;
+}
+
+}  // namespace pe
+
+extern "C" int32_t pe_mse_fwd_bwd_static(const void* pred, int32_t pred_dtype,
+                                         const float* target, const float* joints,
+                                         float* weight, const uint8_t* mask, int32_t B, int32_t K,
+                                         int32_t H, int32_t W, float stride, float sigma,
+                                         int32_t radius, float* loss, float* per_joint,
+                                         void* grad, pe_stream_t stream) {
+    PE_REQUIRE(B > 0 && K > 0, PE_E_INVALID, "pe_mse_fwd_bwd_static: B and K must be positive");
+    PE_REQUIRE((int64_t)B * K <= PE_MSE_STATIC_MAX_MAPS, PE_E_UNSUPPORTED,
+               "pe_mse_fwd_bwd_static: B*K = %lld maps exceeds the static scratch of %d maps; "
+               "use pe_mse_fwd_bwd with a caller workspace",
+               (long long)B * K, PE_MSE_STATIC_MAX_MAPS);
+    float* ptr = nullptr;
+    const int32_t rc = pe::static_scratch(&ptr);
+    if (rc != PE_OK) return rc;
+    // Stage 1 writes partial[0 .. B*K) in full and stage 2 reads nothing beyond it, so what an
+    // earlier (larger) call left behind is never seen and nothing has to be cleared.
+    return pe::mse_run(pred, pred_dtype, target, joints, weight, mask, B, K, H, W, stride, sigma,
+                       radius, loss, per_joint, grad, ptr, stream);
 }
