@@ -422,6 +422,9 @@ int32_t pe_mul_f32(float* a, const float* b, int64_t n, pe_stream_t stream);
  *           stored activation is recomputed with the same operations and rounding, so the
  *           result is bit-identical and one tensor read per pass is saved); both NULL with
  *           a = NULL means no activation.
+ *           frozen != 0 (pe_bn_bwd_bf16, pe_bn_bwd_from_partials_bf16): mean and rstd are the
+ *           layer's running statistics, constants of the step, so dz = gamma*rstd*g; dgamma and
+ *           dbeta as above.
  * C must be a multiple of 8, at most 2048.  workspace: pe_bn_workspace_bytes(M, C).
  * Reductions are ordered: results are bit-stable from run to run.
  * ---------------------------------------------------------------------- */
@@ -437,6 +440,28 @@ int32_t pe_bn_bwd_bf16(const void* da, const void* a, int32_t relu, const void* 
                        const float* gamma, const float* mean, const float* rstd,
                        const float* act_scale, const float* act_shift, float* dgamma,
                        float* dbeta, void* dz, void* dmasked, void* workspace,
+                       int32_t frozen, pe_stream_t stream);
+
+/* Folded constants of batch-norm layers that run on their running statistics (inference, or
+ * training with frozen statistics), for any number of layers in one launch:
+ *   rstd = 1/sqrt(running_var + eps); scale = gamma*rstd; shift = beta - running_mean*scale;
+ *   mean / rstd (may be NULL) receive running_mean / rstd: the rows pe_bn_bwd_bf16 reads.
+ * jobs_device: DEVICE array of njobs records; every pointer in it is a device pointer to C floats.
+ * Replaces the inference graph TensorFlow builds from the same variables (is_training false,
+ * test.ipynb:1004; nets/mobilenet_v2.py, PoseEstimation.pyproj:32, absent). */
+typedef struct pe_bn_fold_job {
+    const float* gamma;
+    const float* beta;
+    const float* running_mean;
+    const float* running_var;
+    float* scale;
+    float* shift;
+    float* mean;
+    float* rstd;
+    int32_t C;
+    int32_t reserved;
+} pe_bn_fold_job;
+int32_t pe_bn_fold_f32(const pe_bn_fold_job* jobs_device, int32_t njobs, float eps,
                        pe_stream_t stream);
 
 /* Backward-data fused with the first half of the batch-norm backward of the layer BELOW: the
@@ -469,7 +494,7 @@ int32_t pe_deconv4x4s2_bwd_data_bnmask_bf16(int32_t B, int32_t H, int32_t W, int
 int32_t pe_bn_bwd_from_partials_bf16(const void* g, const void* z, int32_t rows, int64_t M,
                                      int32_t C, const float* gamma, const float* mean,
                                      const float* rstd, float* dgamma, float* dbeta, void* dz,
-                                     void* workspace, pe_stream_t stream);
+                                     void* workspace, int32_t frozen, pe_stream_t stream);
 
 /* Forward convolutions that also leave the batch-norm statistics of their own output behind,
  * so the training forward pass does not read z again to reduce it.  Same operands as
@@ -532,8 +557,15 @@ int32_t pe_add_bf16(const void* a, const void* b, int64_t n, void* out, pe_strea
  *   pe_comm_unique_id  : one rank makes the 128-byte id and hands it to the others by
  *                        whatever channel launched them.
  *   pe_comm_create     : collective over `world` ranks, on the caller's current GPU.
- *   pe_allreduce_bucket: buf[0..n) = scale * sum over ranks of buf, in place, asynchronous on
- *                        `stream` (scale = 1/world averages; dtype PE_DTYPE_F32 / PE_DTYPE_BF16).
+ *   pe_allreduce_bucket: buf[0..n) = sum over ranks of (scale * buf), in place, asynchronous on
+ *                        `stream` (dtype PE_DTYPE_F32 / PE_DTYPE_BF16).  scale = 1 is a plain
+ *                        sum: the training step passes 1 and folds 1/world into the optimizer
+ *                        (pe_adam_step grad_scale).  Any other scale rides inside the reduction
+ *                        (RCCL's pre-multiplied sum; for bf16 the scale is rounded to bf16), so
+ *                        no second pass reads the bucket.
+ *   pe_grad_pack_bf16 / pe_grad_unpack_bf16: float32 <-> bf16 (round to nearest even) copies of
+ *                        n elements, for exchanging a float32 gradient bucket in bf16 (half the
+ *                        bytes on the links); 16-byte aligned pointers.
  * The Python layer uses torch.distributed (the same RCCL) by default; these are for consumers
  * that have no such layer.
  * ---------------------------------------------------------------------- */
@@ -543,6 +575,8 @@ int32_t pe_comm_create(int32_t rank, int32_t world, const uint8_t id[128], pe_co
 int32_t pe_allreduce_bucket(pe_comm* comm, void* buf, int64_t n, int32_t dtype, float scale,
                             pe_stream_t stream);
 int32_t pe_comm_destroy(pe_comm* comm);
+int32_t pe_grad_pack_bf16(const float* src, void* dst_bf16, int64_t n, pe_stream_t stream);
+int32_t pe_grad_unpack_bf16(const void* src_bf16, float* dst, int64_t n, pe_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * Detection branch: per-anchor targets from ground-truth boxes, and the loss on them.

@@ -320,14 +320,17 @@ def deconv_train_reference(d, state, x_nhwc, da_nhwc, bn_eps: float = 1e-5):
 
 
 def pose_resnet_train_reference(specs, state, img_u8, targets, weights, mask, mean, std,
-                                bn_eps: float = 1e-5, round_bf16: bool = True):
+                                bn_eps: float = 1e-5, round_bf16: bool = True,
+                                frozen_bn: bool = False):
     """One forward/backward of the training graph on the CPU with torch autograd.
 
     targets [B,K,H,W], weights [B,K], mask [B,H,W] or None: as produced by the NumPy oracle
     (render_targets).  Loss = 0.5/(BKHW) * sum m (w (p - t))^2.  With round_bf16 the graph rounds
     to bf16 where the kernels do (weights, every stored activation and activation gradient);
-    without it the graph is plain float32.  Returns (loss, heatmaps, {name: grad}) with grads in
-    framework layouts for every weight / gamma / beta / bias.
+    without it the graph is plain float32.  frozen_bn: every batch norm uses the state's running
+    mean / variance as constants (eval-mode normalisation; gamma and beta still receive
+    gradients).  Returns (loss, heatmaps, {name: grad}) with grads in framework layouts for every
+    weight / gamma / beta / bias.
     """
     stem, blocks, deconvs, final = specs
     rb = _RoundBoth.apply if round_bf16 else (lambda t: t)
@@ -339,8 +342,13 @@ def pose_resnet_train_reference(specs, state, img_u8, targets, weights, mask, me
         P[k] = v.clone().double().float().requires_grad_(True)
 
     def bn(c, z, residual=None, relu=True):
-        y = F.batch_norm(z, None, None, P[c.name + ".bn.gamma"], P[c.name + ".bn.beta"],
-                         training=True, momentum=0.0, eps=bn_eps)
+        if frozen_bn:
+            y = F.batch_norm(z, state[c.name + ".bn.mean"].float(), state[c.name + ".bn.var"].float(),
+                             P[c.name + ".bn.gamma"], P[c.name + ".bn.beta"], training=False,
+                             eps=bn_eps)
+        else:
+            y = F.batch_norm(z, None, None, P[c.name + ".bn.gamma"], P[c.name + ".bn.beta"],
+                             training=True, momentum=0.0, eps=bn_eps)
         if residual is not None:
             y = y + residual
         if relu:

@@ -169,6 +169,8 @@ SIGNATURES = {
     "pe_comm_create": (c_int32, [c_int32, c_int32, c_void_p, c_void_p]),
     "pe_allreduce_bucket": (c_int32, [c_void_p, c_void_p, c_int64, c_int32, c_float, c_void_p]),
     "pe_comm_destroy": (c_int32, [c_void_p]),
+    "pe_grad_pack_bf16": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p]),
+    "pe_grad_unpack_bf16": (c_int32, [c_void_p, c_void_p, c_int64, c_void_p]),
     "pe_depthwise3x3_bwd_data_bf16": (
         c_int32, [c_void_p] + [c_int32] * 6 + [c_void_p, c_void_p, c_void_p]),
     "pe_depthwise3x3_bwd_weight_workspace_bytes": (c_size_t, [c_int32]),
@@ -212,12 +214,13 @@ SIGNATURES = {
                                   c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
     "pe_bn_bwd_from_partials_bf16": (
         c_int32, [c_void_p, c_void_p, c_int32, c_int64, c_int32, c_void_p, c_void_p, c_void_p,
-                  c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+                  c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p]),
     "pe_bn_bwd_bf16": (
         c_int32,
         [c_void_p, c_void_p, c_int32, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p,
-         c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
+         c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p],
     ),
+    "pe_bn_fold_f32": (c_int32, [c_void_p, c_int32, c_float, c_void_p]),
 }
 
 

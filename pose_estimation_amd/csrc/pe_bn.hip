@@ -233,7 +233,8 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
                                                               const float* mean,
                                                               const float* rstd, float* dgamma,
                                                               float* dbeta, float* coefA,
-                                                              float* coefB, float* coefC) {
+                                                              float* coefB, float* coefC,
+                                                              int frozen) {
     float s1, s2;
     const int c = fold_partials(partial, nblk, C, s1, s2);
     if (c >= 0) {
@@ -241,8 +242,26 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
         dgamma[c] = dg;
         dbeta[c] = s1;
         coefA[c] = gamma[c] * rstd[c];
-        coefB[c] = s1 * inv_m;
-        coefC[c] = dg * rstd[c] * inv_m;
+        // frozen statistics: mean and rstd are constants of the layer, so the two terms that
+        // carry the gradient through them vanish and dz = gamma * rstd * g
+        coefB[c] = frozen ? 0.0f : s1 * inv_m;
+        coefC[c] = frozen ? 0.0f : dg * rstd[c] * inv_m;
+    }
+}
+
+// Folded constants of every batch-norm layer of a network in one launch: workgroup j walks the
+// channels of job j.
+__global__ __launch_bounds__(256) void bn_fold_kernel(const pe_bn_fold_job* __restrict__ jobs,
+                                                      float eps) {
+    const pe_bn_fold_job j = jobs[blockIdx.x];
+    for (int c = threadIdx.x; c < j.C; c += 256) {
+        const float mean = j.running_mean[c];
+        const float rstd = 1.0f / sqrtf(j.running_var[c] + eps);
+        const float sc = j.gamma[c] * rstd;
+        j.scale[c] = sc;
+        j.shift[c] = j.beta[c] - mean * sc;
+        if (j.mean) j.mean[c] = mean;
+        if (j.rstd) j.rstd[c] = rstd;
     }
 }
 
@@ -405,7 +424,8 @@ extern "C" int32_t pe_bn_bwd_bf16(const void* da, const void* a, int32_t relu, c
                                   int64_t M, int32_t C, const float* gamma, const float* mean,
                                   const float* rstd, const float* act_scale,
                                   const float* act_shift, float* dgamma, float* dbeta, void* dz,
-                                  void* dmasked, void* workspace, pe_stream_t stream) {
+                                  void* dmasked, void* workspace, int32_t frozen,
+                                  pe_stream_t stream) {
     int32_t rc = bn_check("pe_bn_bwd_bf16", M, C);
     if (rc != PE_OK) return rc;
     PE_REQUIRE(da && z && gamma && mean && rstd && dgamma && dbeta && dz && workspace,
@@ -431,7 +451,8 @@ extern "C" int32_t pe_bn_bwd_bf16(const void* da, const void* a, int32_t relu, c
     if (rc != PE_OK) return rc;
     bn_bwd_finalize_kernel<<<(C + kFoldCh - 1) / kFoldCh, 256, 0, st>>>(partial, g.nblk, C,
                                                            (float)(1.0 / (double)M), gamma, mean,
-                                                           rstd, dgamma, dbeta, coefA, coefB, coefC);
+                                                           rstd, dgamma, dbeta, coefA, coefB, coefC,
+                                                           frozen != 0);
     rc = check_launch("pe_bn_bwd_bf16(finalize)");
     if (rc != PE_OK) return rc;
     const long nchunk = M * (C / 8);
@@ -446,7 +467,8 @@ extern "C" int32_t pe_bn_bwd_from_partials_bf16(const void* g, const void* z, in
                                                 int64_t M, int32_t C, const float* gamma,
                                                 const float* mean, const float* rstd,
                                                 float* dgamma, float* dbeta, void* dz,
-                                                void* workspace, pe_stream_t stream) {
+                                                void* workspace, int32_t frozen,
+                                                pe_stream_t stream) {
     int32_t rc = bn_check("pe_bn_bwd_from_partials_bf16", M, C);
     if (rc != PE_OK) return rc;
     PE_REQUIRE(g && z && gamma && mean && rstd && dgamma && dbeta && dz && workspace && rows > 0,
@@ -463,7 +485,7 @@ extern "C" int32_t pe_bn_bwd_from_partials_bf16(const void* g, const void* z, in
     hipStream_t st = as_stream(stream);
     bn_bwd_finalize_kernel<<<(C + kFoldCh - 1) / kFoldCh, 256, 0, st>>>(
         partial, rows, C, (float)(1.0 / (double)M), gamma, mean, rstd, dgamma, dbeta, coefA, coefB,
-        coefC);
+        coefC, frozen != 0);
     rc = check_launch("pe_bn_bwd_from_partials_bf16(finalize)");
     if (rc != PE_OK) return rc;
     const long nchunk = M * (C / 8);
@@ -472,4 +494,14 @@ extern "C" int32_t pe_bn_bwd_from_partials_bf16(const void* g, const void* z, in
         static_cast<const uint16_t*>(g), nullptr, static_cast<const uint16_t*>(z), nchunk, C / 8,
         mean, coefA, coefB, coefC, INFINITY, nullptr, nullptr, static_cast<uint16_t*>(dz), nullptr);
     return check_launch("pe_bn_bwd_from_partials_bf16(apply)");
+}
+
+extern "C" int32_t pe_bn_fold_f32(const pe_bn_fold_job* jobs_device, int32_t njobs, float eps,
+                                  pe_stream_t stream) {
+    if (njobs == 0) return PE_OK;
+    PE_REQUIRE(jobs_device != nullptr && njobs > 0, PE_E_INVALID,
+               "pe_bn_fold_f32: NULL job table or negative count");
+    PE_REQUIRE(eps >= 0.0f && isfinite(eps), PE_E_INVALID, "pe_bn_fold_f32: eps must be >= 0");
+    bn_fold_kernel<<<(unsigned)njobs, 256, 0, as_stream(stream)>>>(jobs_device, eps);
+    return check_launch("pe_bn_fold_f32");
 }

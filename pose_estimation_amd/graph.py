@@ -173,6 +173,7 @@ class TrainGraph:
         # backward-data GEMMs mask their result and reduce it for the batch norm below them
         # whenever that layer's output has no other reader (PE_FUSE_BN_BWD=0: separate passes)
         self.fuse_bn_bwd = os.environ.get("PE_FUSE_BN_BWD", "1") != "0"
+        self.freeze_bn = False
         # ... when the GEMM's reduction is long enough to carry the heavier epilogue: with a
         # short one (a pointwise conv from 64 channels) the separate pass measured faster
         self.fuse_min_k = int(os.environ.get("PE_FUSE_MIN_K", "256"))
@@ -216,15 +217,40 @@ class TrainGraph:
         self.refresh_transposes()
 
     def fold_bn(self) -> None:
-        """Inference epilogue constants from the running statistics."""
-        for L in self.layers:
-            if L.kind == "head":
-                continue
-            gamma = self.view(self.master, L.name + ".bn.gamma")
-            beta = self.view(self.master, L.name + ".bn.beta")
-            sc = gamma / torch.sqrt(self.bn_var[L.name] + BN_EPS)
-            self.scale[L.name] = sc.contiguous()
-            self.shift[L.name] = (beta - self.bn_mean[L.name] * sc).contiguous()
+        """Inference epilogue constants from the running statistics: every layer in one launch,
+        written in place."""
+        if getattr(self, "_fold_plan", None) is None:
+            plan = pnn.BnFoldPlan(self.device)
+            for L in self.layers:
+                if L.kind == "head":
+                    continue
+                C = self.bn_var[L.name].numel()
+                self.scale[L.name] = torch.empty(C, dtype=torch.float32, device=self.device)
+                self.shift[L.name] = torch.empty(C, dtype=torch.float32, device=self.device)
+                plan.add(self.view(self.master, L.name + ".bn.gamma"),
+                         self.view(self.master, L.name + ".bn.beta"), self.bn_mean[L.name],
+                         self.bn_var[L.name], self.scale[L.name], self.shift[L.name])
+            self._fold_plan = plan
+        self._fold_plan.run(BN_EPS)
+
+    def freeze_batch_norm(self, on: bool = True) -> None:
+        """Frozen statistics: every batch norm normalises with its running mean and variance,
+        which no longer move, and backward treats them as constants (gamma and beta still
+        train).  With them N ranks x B/N images give the gradient of one rank x B images."""
+        self.freeze_bn = bool(on)
+
+    def _refresh_frozen_rows(self) -> None:
+        if getattr(self, "_freeze_plan", None) is None:
+            plan = pnn.BnFoldPlan(self.device)
+            for L in self.layers:
+                if L.kind == "head":
+                    continue
+                r = self.bn_rows[L.name]
+                plan.add(self.view(self.master, L.name + ".bn.gamma"),
+                         self.view(self.master, L.name + ".bn.beta"), self.bn_mean[L.name],
+                         self.bn_var[L.name], r[2], r[3], mean=r[0], rstd=r[1])
+            self._freeze_plan = plan
+        self._freeze_plan.run(BN_EPS)
 
     def refresh_transposes(self) -> None:
         """Re-packs every weight for the backward-data GEMMs (one launch for all layers)."""
@@ -239,10 +265,14 @@ class TrainGraph:
             self._tplan = plan
         self._tplan.run()
 
-    def enable_data_parallel(self, bucket_bytes: int = 32 << 20, group=None) -> None:
-        """Call after torch.distributed is initialised; parameters must already be identical on
-        every rank (same seed / same loaded state, or broadcast_parameters())."""
-        self.bucketer = GradBucketer(self.grads, self.layer_starts, bucket_bytes, group)
+    def enable_data_parallel(self, bucket_bytes: int = 32 << 20, group=None, comm=None,
+                             transport: str = "f32") -> None:
+        """Call after torch.distributed is initialised (or pass comm = a parallel.NativeComm to
+        exchange gradients through the library's own RCCL communicator); parameters must already
+        be identical on every rank (same seed / same loaded state, or broadcast_parameters()).
+        transport "bf16" halves the bytes on the links (gradients summed in bf16)."""
+        self.bucketer = GradBucketer(self.grads, self.layer_starts, bucket_bytes, group,
+                                     comm=comm, transport=transport)
 
     def broadcast_parameters(self, src: int = 0) -> None:
         import torch.distributed as dist
@@ -263,6 +293,8 @@ class TrainGraph:
     def begin(self, training: bool) -> None:
         self.training = training
         self.tape = []
+        if training and self.freeze_bn:
+            self._refresh_frozen_rows()
 
     def unit(self, L: Layer, x: Var, residual: Optional[Var] = None,
              relu: Optional[int] = None) -> Var:
@@ -292,9 +324,13 @@ class TrainGraph:
             # bandwidth-bound conv without an epilogue, then one reduction pass for the statistics
             z = pnn.depthwise3x3(x.t, self.w(L), None, None, L.stride, L.dilation, relu=0)
             M = z.numel() // L.cout
-            _, _, scale, shift = pnn.bn_stats(z, gamma, beta, BN_EPS, self.bn_momentum,
-                                              self.bn_mean[L.name], self.bn_var[L.name],
-                                              self._workspace_for(M, L.cout), out=self.bn_buf[L.name])
+            if self.freeze_bn:
+                scale, shift = self.bn_rows[L.name][2], self.bn_rows[L.name][3]
+            else:
+                _, _, scale, shift = pnn.bn_stats(z, gamma, beta, BN_EPS, self.bn_momentum,
+                                                  self.bn_mean[L.name], self.bn_var[L.name],
+                                                  self._workspace_for(M, L.cout),
+                                                  out=self.bn_buf[L.name])
             out = Var(pnn.bn_apply(z, scale, shift, res_t, act))
             if act and residual is None:
                 out.prod = (L, z, act)
@@ -309,9 +345,12 @@ class TrainGraph:
             M = B * Ho * Wo
             z, rows = pnn.conv2d_bnstats(x.t, self.w(L), self._workspace_for(M, L.cout), L.stride,
                                          L.pad, **kw)
-        _, _, scale, shift = pnn.bn_finalize(
-            self._ws, rows, M, L.cout, gamma, beta, BN_EPS, self.bn_momentum,
-            self.bn_mean[L.name], self.bn_var[L.name], out=self.bn_rows[L.name])
+        if self.freeze_bn:
+            scale, shift = self.bn_rows[L.name][2], self.bn_rows[L.name][3]
+        else:
+            _, _, scale, shift = pnn.bn_finalize(
+                self._ws, rows, M, L.cout, gamma, beta, BN_EPS, self.bn_momentum,
+                self.bn_mean[L.name], self.bn_var[L.name], out=self.bn_rows[L.name])
         out = Var(pnn.bn_apply(z, scale, shift, res_t, act))
         if act and residual is None:
             out.prod = (L, z, act)
@@ -422,7 +461,8 @@ class TrainGraph:
                                                  zb, buf[2], buf[3], ws, relu=actb)
             x.dz = pnn.bn_bwd_from_partials(
                 g, zb, rows, self.view(self.master, Lb.name + ".bn.gamma"), buf[0], buf[1],
-                self._g(Lb.name + ".bn.gamma"), self._g(Lb.name + ".bn.beta"), ws)
+                self._g(Lb.name + ".bn.gamma"), self._g(Lb.name + ".bn.beta"), ws,
+                frozen=self.freeze_bn)
             x.grad = g
             return
         fused = x.grad is not None and not (L.k == 1 and L.stride == 2)
@@ -478,7 +518,7 @@ class TrainGraph:
                                    self._g(L.name + ".bn.gamma"), self._g(L.name + ".bn.beta"),
                                    self._workspace_for(z.numel() // L.cout, L.cout), masked,
                                    relu=act or 1, act_scale=buf[2] if rebuild else None,
-                                   act_shift=buf[3] if rebuild else None)
+                                   act_shift=buf[3] if rebuild else None, frozen=self.freeze_bn)
                 if residual is not None:
                     self._acc(residual, g if masked else out.grad)
                 self._weight_grad(L, x.t, dz)

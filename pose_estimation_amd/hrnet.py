@@ -232,17 +232,23 @@ class PoseHRNet:
 
     def load_state(self, st: Dict[str, torch.Tensor]) -> None:
         self.p.clear()
+        plan, keep = pnn.BnFoldPlan(self.device), []
         for u in all_units(self.spec):
             w = st[u.name + ".weight"]
             if u.name == "stem.conv1":
                 pw = pnn.pack_stem3x3_weight(w)
             else:
                 pw = self._pack(w)
-            sc = st[u.name + ".bn.gamma"] / torch.sqrt(st[u.name + ".bn.var"] + BN_EPS)
-            sh = st[u.name + ".bn.beta"] - st[u.name + ".bn.mean"] * sc
             self.p[u.name + ".weight"] = pw.to(self.device)
-            self.p[u.name + ".scale"] = sc.float().contiguous().to(self.device)
-            self.p[u.name + ".shift"] = sh.float().contiguous().to(self.device)
+            src = tuple(st[u.name + k].float().contiguous().to(self.device)
+                        for k in (".bn.gamma", ".bn.beta", ".bn.mean", ".bn.var"))
+            keep.append(src)
+            C = src[0].numel()
+            self.p[u.name + ".scale"] = torch.empty(C, dtype=torch.float32, device=self.device)
+            self.p[u.name + ".shift"] = torch.empty(C, dtype=torch.float32, device=self.device)
+            plan.add(*src, self.p[u.name + ".scale"], self.p[u.name + ".shift"])
+        plan.run(BN_EPS)               # every layer's folded constants in one launch
+        torch.cuda.synchronize(self.device)
         self.p["final.weight"] = self._pack(st["final.weight"]).to(self.device)
         self.p["final.bias"] = st["final.bias"].float().to(self.device)
 

@@ -171,14 +171,19 @@ class PoseMobileNetV2:
 
     # ------------------------------------------------------------------ parameters
     def _fold(self, st, name, cout_pad):
-        sc = st[name + ".bn.gamma"] / torch.sqrt(st[name + ".bn.var"] + BN_EPS)
-        sh = st[name + ".bn.beta"] - st[name + ".bn.mean"] * sc
-        scp = torch.zeros(cout_pad)
-        shp = torch.zeros(cout_pad)
-        scp[:sc.numel()] = sc
-        shp[:sh.numel()] = sh
-        self.p[name + ".scale"] = scp.to(self.device)
-        self.p[name + ".shift"] = shp.to(self.device)
+        """Queues the layer's folded constants (padded channels: gamma = 0 -> scale = shift = 0);
+        load_state computes all of them with one pe_bn_fold_f32 launch."""
+        def up(key, fill):
+            t = torch.full((cout_pad,), fill, dtype=torch.float32)
+            v = st[name + key].float().reshape(-1)
+            t[:v.numel()] = v
+            return t.to(self.device)
+
+        self.p[name + ".scale"] = torch.empty(cout_pad, dtype=torch.float32, device=self.device)
+        self.p[name + ".shift"] = torch.empty(cout_pad, dtype=torch.float32, device=self.device)
+        src = (up(".bn.gamma", 0.0), up(".bn.beta", 0.0), up(".bn.mean", 0.0), up(".bn.var", 1.0))
+        self._fold_src.append(src)     # kept alive until the launch has read them
+        self._fold_plan.add(*src, self.p[name + ".scale"], self.p[name + ".shift"])
 
     def _pointwise(self, st, name, cin, cout, fold=True):
         w = torch.zeros(pad8(cout) if fold else cout, pad8(cin), 1, 1)
@@ -196,6 +201,8 @@ class PoseMobileNetV2:
 
     def load_state(self, st: Dict[str, torch.Tensor]) -> None:
         self.p.clear()
+        self._fold_plan = pnn.BnFoldPlan(self.device)
+        self._fold_src = []
         sc = pad8(st["stem.weight"].shape[0])
         self.p["stem.weight"] = torch.zeros(sc, 2, 64, dtype=BF16)
         self.p["stem.weight"][:st["stem.weight"].shape[0]] = pnn.pack_stem3x3_weight(st["stem.weight"])
@@ -213,6 +220,9 @@ class PoseMobileNetV2:
         self._pointwise(st, "heat", cf, self.num_joints, fold=False)
         if self.num_pairs:
             self._pointwise(st, "vec", cf, 4 * self.num_pairs, fold=False)
+        self._fold_plan.run(BN_EPS)
+        torch.cuda.synchronize(self.device)
+        self._fold_plan, self._fold_src = None, []
 
     # ------------------------------------------------------------------ inference
     def forward_features(self, x_s2d: torch.Tensor) -> torch.Tensor:

@@ -175,6 +175,7 @@ class PoseResNet:
         self.bn_var = {c.name: torch.ones(c.cout, device=self.device) for c in self.convs if c.bn}
         self.scale: Dict[str, Optional[torch.Tensor]] = {}
         self.shift: Dict[str, Optional[torch.Tensor]] = {}
+        self._fold_plan = None
 
     # ------------------------------------------------------------------ parameters
     def view(self, arena: torch.Tensor, name: str) -> torch.Tensor:
@@ -207,17 +208,23 @@ class PoseResNet:
         self.fold_bn()
 
     def fold_bn(self) -> None:
-        """Inference epilogue constants: scale = gamma/sqrt(var+eps), shift = beta - mean*scale."""
-        for c in self.convs:
-            if c.bn:
-                gamma = self.view(self.master, c.name + ".bn.gamma")
-                beta = self.view(self.master, c.name + ".bn.beta")
-                sc = gamma / torch.sqrt(self.bn_var[c.name] + BN_EPS)
-                self.scale[c.name] = sc.contiguous()
-                self.shift[c.name] = (beta - self.bn_mean[c.name] * sc).contiguous()
-            else:
-                self.scale[c.name] = None
-                self.shift[c.name] = self.view(self.master, c.name + ".bias").clone()
+        """Inference epilogue constants: scale = gamma/sqrt(var+eps), shift = beta - mean*scale,
+        for every layer in one launch, written in place (the tensors in self.scale / self.shift
+        keep their addresses)."""
+        if self._fold_plan is None:
+            plan = pnn.BnFoldPlan(self.device)
+            for c in self.convs:
+                if c.bn:
+                    self.scale[c.name] = torch.empty(c.cout, dtype=torch.float32, device=self.device)
+                    self.shift[c.name] = torch.empty(c.cout, dtype=torch.float32, device=self.device)
+                    plan.add(self.view(self.master, c.name + ".bn.gamma"),
+                             self.view(self.master, c.name + ".bn.beta"), self.bn_mean[c.name],
+                             self.bn_var[c.name], self.scale[c.name], self.shift[c.name])
+                else:
+                    self.scale[c.name] = None
+                    self.shift[c.name] = self.view(self.master, c.name + ".bias")
+            self._fold_plan = plan
+        self._fold_plan.run(BN_EPS)
 
     def w(self, c: ConvSpec) -> torch.Tensor:
         return self.view(self.work, c.name + ".weight")

@@ -468,6 +468,50 @@ class TransposePlan:
                 torch.cuda.current_stream(self.device).cuda_stream))
 
 
+class BnFoldPlan:
+    """The batch-norm layers of a network whose folded constants (scale = gamma / sqrt(var + eps),
+    shift = beta - mean * scale) are produced together by one launch (pe_bn_fold_f32).  The
+    tensors must stay alive and in place for the life of the plan; run() reads their current
+    values, so it is called again after the parameters or running statistics changed."""
+
+    _DTYPE = np.dtype([("gamma", np.uint64), ("beta", np.uint64), ("running_mean", np.uint64),
+                       ("running_var", np.uint64), ("scale", np.uint64), ("shift", np.uint64),
+                       ("mean", np.uint64), ("rstd", np.uint64), ("C", np.int32),
+                       ("reserved", np.int32)])
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+        self._jobs = []
+        self._table = None
+
+    def add(self, gamma, beta, running_mean, running_var, scale, shift, mean=None, rstd=None):
+        ts = [gamma, beta, running_mean, running_var, scale, shift]
+        opt = [t for t in (mean, rstd) if t is not None]
+        _need_gpu(*ts, *opt)
+        C = gamma.numel()
+        for t in ts + opt:
+            if t.dtype != torch.float32 or t.numel() != C or not t.is_contiguous():
+                raise ValueError("bn fold operands must be contiguous float32 of one length")
+        self._jobs.append(tuple(t.data_ptr() for t in ts)
+                          + (_ptr(mean) or 0, _ptr(rstd) or 0, C, 0))
+        self._table = None
+
+    def __len__(self) -> int:
+        return len(self._jobs)
+
+    def run(self, eps: float) -> None:
+        if not self._jobs:
+            return
+        if self._table is None:
+            rec = np.zeros(len(self._jobs), dtype=self._DTYPE)
+            for i, job in enumerate(self._jobs):
+                rec[i] = job
+            self._table = torch.from_numpy(rec.view(np.uint8)).to(self.device)
+        with torch.cuda.device(self.device):
+            check(lib().pe_bn_fold_f32(self._table.data_ptr(), len(self._jobs), float(eps),
+                                       torch.cuda.current_stream(self.device).cuda_stream))
+
+
 _narrow_layouts: dict = {}
 
 
@@ -636,7 +680,7 @@ def deconv4x4s2_bwd_data_bnmask(dy: torch.Tensor, w_t: torch.Tensor, z: torch.Te
 
 
 def bn_bwd_from_partials(g: torch.Tensor, z: torch.Tensor, rows: int, gamma, mean, rstd, dgamma,
-                         dbeta, ws: torch.Tensor, dz=None) -> torch.Tensor:
+                         dbeta, ws: torch.Tensor, dz=None, frozen: bool = False) -> torch.Tensor:
     """Second half of the fused batch-norm backward: folds the `rows` partial rows a *_bnmask
     backward-data call left in `ws` and returns dz."""
     _check_act(g, "g")
@@ -649,7 +693,7 @@ def bn_bwd_from_partials(g: torch.Tensor, z: torch.Tensor, rows: int, gamma, mea
                                                  gamma.data_ptr(), mean.data_ptr(),
                                                  rstd.data_ptr(), dgamma.data_ptr(),
                                                  dbeta.data_ptr(), dz.data_ptr(), ws.data_ptr(),
-                                                 _stream(z)))
+                                                 int(bool(frozen)), _stream(z)))
     return dz
 
 
@@ -832,11 +876,11 @@ def bn_apply(z: torch.Tensor, scale, shift, residual=None, relu: int = 1,
 
 def bn_bwd(da: torch.Tensor, a: Optional[torch.Tensor], z: torch.Tensor, gamma, mean, rstd,
            dgamma, dbeta, ws: torch.Tensor, want_masked: bool = False, dz=None, relu: int = 1,
-           act_scale=None, act_shift=None):
+           act_scale=None, act_shift=None, frozen: bool = False):
     """Returns (dz, g) where g = da masked by the activation that produced `a` (relu 1: ReLU,
     2: ReLU6; no mask when a is None); g is None unless want_masked.  For a layer without a
     residual, a = None with act_scale / act_shift (what its bn_apply used) rebuilds the mask from
-    z instead of reading the stored activation."""
+    z instead of reading the stored activation.  frozen: mean / rstd are running statistics."""
     _check_act(da, "da")
     C = z.shape[3]
     M = z.numel() // C
@@ -849,5 +893,5 @@ def bn_bwd(da: torch.Tensor, a: Optional[torch.Tensor], z: torch.Tensor, gamma, 
                                    mean.data_ptr(), rstd.data_ptr(), _ptr(act_scale),
                                    _ptr(act_shift), dgamma.data_ptr(),
                                    dbeta.data_ptr(), dz.data_ptr(), _ptr(g), ws.data_ptr(),
-                                   _stream(z)))
+                                   int(bool(frozen)), _stream(z)))
     return dz, g

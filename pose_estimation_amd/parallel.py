@@ -53,23 +53,105 @@ def make_buckets(boundaries: Sequence[int], total: int, bucket_elems: int,
     return buckets
 
 
+class _HostStagedExchange:
+    """gloo has no device collectives that survive more than one round on this stack, so a
+    rehearsal of the N > 1 path on one GPU sums buckets on the host.  It keeps the ordering the
+    RCCL path has: a bucket is reduced BEHIND an event recorded on the stream that produced it,
+    on a stream of its own, while the caller keeps enqueueing backward kernels; finish() makes
+    the caller's stream wait for every bucket.  One worker thread issues the collectives in
+    submission order, which is the same on every rank."""
+
+    def __init__(self, dist, group, device):
+        import queue
+        import threading
+
+        self.dist, self.group, self.device = dist, group, device
+        self.stream = torch.cuda.Stream(device=device)
+        self.q: "queue.Queue" = queue.Queue()
+        self.done: List[torch.cuda.Event] = []
+        self.error: Optional[BaseException] = None
+        self.thread = threading.Thread(target=self._run, daemon=True)
+        self.thread.start()
+
+    def _run(self) -> None:
+        torch.cuda.set_device(self.device)
+        while True:
+            item = self.q.get()
+            try:
+                if item is None:
+                    return
+                view, ready = item
+                if self.error is None:
+                    ready.synchronize()                      # the producer's kernels are done
+                    with torch.cuda.stream(self.stream):
+                        host = view.to("cpu", non_blocking=False)
+                        self.dist.all_reduce(host, op=self.dist.ReduceOp.SUM, group=self.group)
+                        view.copy_(host, non_blocking=False)
+                        ev = torch.cuda.Event()
+                        ev.record(self.stream)
+                    self.done.append(ev)
+            except BaseException as exc:  # noqa: BLE001 - re-raised on the caller's thread
+                self.error = exc
+            finally:
+                self.q.task_done()
+
+    def submit(self, view: torch.Tensor) -> None:
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream(self.device))
+        self.q.put((view, ready))
+
+    def finish(self) -> None:
+        self.q.join()
+        if self.error is not None:
+            err, self.error = self.error, None
+            raise err
+        cur = torch.cuda.current_stream(self.device)
+        for ev in self.done:
+            cur.wait_event(ev)
+        self.done.clear()
+
+    def close(self) -> None:
+        self.q.put(None)
+
+
 class GradBucketer:
-    """Issues one all-reduce per bucket as backward passes the bucket's lowest layer."""
+    """Issues one all-reduce per bucket as backward passes the bucket's lowest layer.
+
+    Backends, all behind the same layer_done() / finish() pair:
+      * torch.distributed "nccl" (RCCL): async collectives on the communicator's stream;
+      * comm=NativeComm: the library's own RCCL communicator (pe_allreduce_bucket) on a stream
+        of this object, ordered by events -- no torch.distributed involved;
+      * torch.distributed "gloo" with a GPU arena: host-staged rehearsal (_HostStagedExchange);
+      * torch.distributed "gloo" with a CPU arena: async collectives (CPU tests).
+    transport="bf16" sends each bucket as bf16 (half the bytes on the links): the float32
+    bucket is packed into a staging buffer, summed in bf16 and unpacked over the bucket.
+    The sum is never scaled here: the optimizer applies grad_scale = 1/world.
+    """
 
     def __init__(self, arena: torch.Tensor, boundaries: Sequence[int],
-                 bucket_bytes: int = 32 << 20, group=None, tail_bytes: Optional[int] = None):
+                 bucket_bytes: int = 32 << 20, group=None, tail_bytes: Optional[int] = None,
+                 comm: Optional["NativeComm"] = None, transport: str = "f32"):
         import torch.distributed as dist
 
+        if transport not in ("f32", "bf16"):
+            raise ValueError("transport must be 'f32' or 'bf16'")
+        if transport == "bf16" and not arena.is_cuda:
+            raise ValueError("bf16 transport packs on the GPU: the arena must be a GPU tensor")
         self.dist = dist
         self.group = group
         self.arena = arena
-        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
-        # RCCL (and gloo on CPU tensors) overlap with backward through async ops.  gloo on GPU
-        # tensors exists only to rehearse the N > 1 path on a one-GPU box; its device-tensor
-        # collectives stall from the second round on (observed on ROCm), so that combination
-        # stages each bucket through host memory and reduces it synchronously.
-        backend = dist.get_backend(group) if dist.is_initialized() else "none"
-        self._staged = backend == "gloo" and arena.is_cuda
+        self.comm = comm
+        self.transport = transport
+        if comm is not None:
+            self.world = comm.world
+            backend = "native"
+        else:
+            self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+            backend = dist.get_backend(group) if dist.is_initialized() else "none"
+        self.backend = backend
+        self._staged = (_HostStagedExchange(dist, group, arena.device)
+                        if backend == "gloo" and arena.is_cuda else None)
+        self._comm_stream = torch.cuda.Stream(device=arena.device) if comm is not None else None
         elems = max(1, bucket_bytes // arena.element_size())
         if tail_bytes is None:
             tail_bytes = bucket_bytes // 8
@@ -77,33 +159,78 @@ class GradBucketer:
                                     max(1, tail_bytes // arena.element_size()))
         self._ready_at = {start: (start, end) for (start, end) in self.buckets}
         self._pending: List = []
+        # bf16 transport: one staging buffer per bucket (68 MB for the 34 M-parameter arena), so
+        # buckets in flight never share memory
+        self._stage = {}
+        if transport == "bf16":
+            for (start, end) in self.buckets:
+                self._stage[start] = torch.empty(end - start, dtype=torch.bfloat16,
+                                                 device=arena.device)
 
     @property
     def grad_scale(self) -> float:
         return 1.0 / self.world
 
+    # ---- one bucket ------------------------------------------------------------------
+    def _pack(self, view: torch.Tensor, stage: torch.Tensor) -> None:
+        from ._ffi import check, lib
+
+        check(lib().pe_grad_pack_bf16(view.data_ptr(), stage.data_ptr(), view.numel(),
+                                      torch.cuda.current_stream(view.device).cuda_stream))
+
+    def _unpack(self, stage: torch.Tensor, view: torch.Tensor) -> None:
+        from ._ffi import check, lib
+
+        check(lib().pe_grad_unpack_bf16(stage.data_ptr(), view.data_ptr(), view.numel(),
+                                        torch.cuda.current_stream(view.device).cuda_stream))
+
     def layer_done(self, layer_start: int) -> None:
         """Call after the gradient of the layer starting at `layer_start` (and of every layer
         above it) has been enqueued on the current stream."""
-        if self.world == 1:
+        if self.world == 1 and self.comm is None:
             return
         b = self._ready_at.get(layer_start)
         if b is None:
             return
         start, end = b
         view = self.arena[start:end]
-        if self._staged:
-            host = view.cpu()
-            self.dist.all_reduce(host, op=self.dist.ReduceOp.SUM, group=self.group)
-            view.copy_(host)
-            return
-        self._pending.append(self.dist.all_reduce(view, op=self.dist.ReduceOp.SUM,
-                                                  group=self.group, async_op=True))
+        stage = self._stage.get(start)
+        payload = view
+        if stage is not None:
+            self._pack(view, stage)        # on the producing stream, right behind the gradients
+            payload = stage
+        if self.comm is not None:
+            cur = torch.cuda.current_stream(view.device)
+            ready = torch.cuda.Event()
+            ready.record(cur)
+            self._comm_stream.wait_event(ready)
+            with torch.cuda.stream(self._comm_stream):
+                self.comm.all_reduce_(payload)
+                done = torch.cuda.Event()
+                done.record(self._comm_stream)
+            self._pending.append((done, stage, view))
+        elif self._staged is not None:
+            self._staged.submit(payload)
+            self._pending.append((None, stage, view))
+        else:
+            work = self.dist.all_reduce(payload, op=self.dist.ReduceOp.SUM, group=self.group,
+                                        async_op=True)
+            self._pending.append((work, stage, view))
 
     def finish(self) -> None:
-        """Make the current stream (or the host, on CPU) wait for every issued bucket."""
-        for w in self._pending:
-            w.wait()
+        """Make the current stream (or the host, on CPU) wait for every issued bucket; with
+        bf16 transport the summed buckets are unpacked over the float32 arena here."""
+        if self._staged is not None:
+            self._staged.finish()
+        for handle, stage, view in self._pending:
+            if handle is None:
+                pass
+            elif isinstance(handle, torch.cuda.Event):
+                torch.cuda.current_stream(view.device).wait_event(handle)
+            else:
+                handle.wait()
+            if stage is not None:
+                self._unpack(stage, view)
         self._pending.clear()
 
     def reduce_all_now(self) -> None:
@@ -111,6 +238,11 @@ class GradBucketer:
         for (start, _end) in self.buckets:
             self.layer_done(start)
         self.finish()
+
+    def close(self) -> None:
+        if self._staged is not None:
+            self._staged.close()
+            self._staged = None
 
 
 class NativeComm:
@@ -142,7 +274,8 @@ class NativeComm:
         return bytes(buf)
 
     def all_reduce_(self, t: torch.Tensor, scale: float = 1.0) -> torch.Tensor:
-        """t = scale * sum over ranks of t, in place, asynchronous on torch's current stream."""
+        """t = sum over ranks of scale * t, in place, asynchronous on torch's current stream
+        (the scale rides inside the reduction; 1.0 is a plain sum)."""
         if not t.is_cuda or not t.is_contiguous() or t.dtype not in (torch.float32, torch.bfloat16):
             raise ValueError("all_reduce_: contiguous float32 / bfloat16 GPU tensor")
         dt = 0 if t.dtype == torch.float32 else 1

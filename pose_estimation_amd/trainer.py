@@ -31,6 +31,13 @@ class Trainer:
         self.device = torch.device(device)
         self.net: Optional[TrainablePoseResNet] = None
         self.global_step = 0
+        self._folded_at = -1     # global_step at which the inference constants were last folded
+
+    @staticmethod
+    def _rank() -> int:
+        import torch.distributed as dist
+
+        return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
 
     # ------------------------------------------------------------------ model
     def build_model(self, state: Optional[Dict[str, torch.Tensor]] = None, seed: int = 3):
@@ -117,15 +124,21 @@ class Trainer:
         s = int(self.model_cfg.heatmap_stride)
         sigma = float(self.model_cfg.sigma)
         i = 0
+        rank = self._rank()      # every data-parallel rank draws its own shard of the batch
+        aug = bool(getattr(self.train_cfg, "augmentation", None))
         while num_batches is None or i < num_batches:
-            seed = int(self.data_cfg.seed) + 1000 * i
+            seed = int(self.data_cfg.seed) + 1000 * i + 100003 * rank
             img = torch.from_numpy(synthetic.images_u8(B, H, W, seed + 1)).to(self.device)
             joints = torch.from_numpy(synthetic.joints(B, K, H, W, seed + 2)).to(self.device)
             mask = torch.from_numpy(synthetic.ignore_mask(B, H // s, W // s, seed + 4)).to(self.device)
             radius = self.model_cfg.get("radius")
             hm, w = ops.render_targets(joints, H // s, W // s, float(s), sigma,
                                        None if radius is None else int(radius), layout="NHWC")
-            labels = {"heatmaps": hm, "masks": mask, "joints": joints, "weights": w}
+            labels = {"heatmaps": hm, "joints": joints, "weights": w}
+            if not aug:
+                # an ignore mask is tied to the frame it was drawn on: with augmentation
+                # configured, train_step re-maps frames and joints and takes no mask
+                labels["masks"] = mask
             pairs = self.model_cfg.get("pairs")
             if pairs:   # the reference's second dense label (test.ipynb:925-944)
                 labels["vecmaps"] = ops.render_vecmaps(joints, [tuple(p) for p in pairs], H // s,
@@ -163,7 +176,7 @@ class Trainer:
                     B, src_hw, (H, W), tuple(aug_cfg.get("scale_range", (1.0, 1.0))),
                     bool(aug_cfg.get("flip_left_right", False)),
                     bool(aug_cfg.get("random_crop", False)),
-                    seed=int(self.data_cfg.seed) + 7919 * self.global_step)
+                    seed=int(self.data_cfg.seed) + 7919 * self.global_step + 104729 * self._rank())
             else:
                 prm = augment.resize_params(B, src_hw, (H, W))
             prm_t = torch.from_numpy(prm).to(images.device)
@@ -198,7 +211,9 @@ class Trainer:
     def predict(self, images_u8: torch.Tensor) -> torch.Tensor:
         """uint8 [B,H,W,3] -> float32 heat maps [B,K,H/4,W/4] (running BN statistics)."""
         net = self._need_model()
-        net.fold_bn()
+        if self._folded_at != self.global_step:   # parameters moved since the last fold
+            net.fold_bn()
+            self._folded_at = self.global_step
         return net.predict(images_u8)
 
     def decode(self, heatmaps: torch.Tensor, layout: str = "NCHW"):
@@ -207,7 +222,11 @@ class Trainer:
 
     # ------------------------------------------------------------------ checkpoint
     def save(self, path: str) -> None:
+        """Writes the checkpoint from rank 0 only (data-parallel ranks hold identical parameters;
+        the running batch-norm statistics saved are rank 0's)."""
         net = self._need_model()
+        if self._rank() != 0:
+            return
         torch.save({"master": net.master.cpu(), "opt_m": net.opt_m.cpu(), "opt_v": net.opt_v.cpu(),
                     "bn_mean": {k: v.cpu() for k, v in net.bn_mean.items()},
                     "bn_var": {k: v.cpu() for k, v in net.bn_var.items()},
@@ -228,3 +247,4 @@ class Trainer:
         net.work.copy_(net.master)
         net.refresh_transposes()
         net.fold_bn()
+        self._folded_at = self.global_step

@@ -65,16 +65,41 @@ class TrainablePoseResNet(PoseResNet):
         # output gradient, nothing downstream reads them before the optimizer, and at batch 64
         # many backward kernels leave CUs idle, so they fill in beside the backward-data chain.
         self.wgrad_stream: Optional[torch.cuda.Stream] = torch.cuda.Stream(device=dev)
+        self.freeze_bn = False
+        self._freeze_plan = None
 
     # ------------------------------------------------------------------ set-up
     def load_state(self, state) -> None:
         super().load_state(state)
         self.refresh_transposes()
 
-    def enable_data_parallel(self, bucket_bytes: int = 32 << 20, group=None) -> None:
-        """Call after torch.distributed is initialised; parameters must already be identical on
-        every rank (same seed / same loaded state, or broadcast_parameters())."""
-        self.bucketer = GradBucketer(self.grads, self.layer_starts, bucket_bytes, group)
+    def enable_data_parallel(self, bucket_bytes: int = 32 << 20, group=None, comm=None,
+                             transport: str = "f32") -> None:
+        """Call after torch.distributed is initialised (or pass comm = a parallel.NativeComm to
+        exchange gradients through the library's own RCCL communicator); parameters must already
+        be identical on every rank (same seed / same loaded state, or broadcast_parameters()).
+        transport "bf16" halves the bytes on the links (gradients summed in bf16)."""
+        self.bucketer = GradBucketer(self.grads, self.layer_starts, bucket_bytes, group,
+                                     comm=comm, transport=transport)
+
+    def freeze_batch_norm(self, on: bool = True) -> None:
+        """Frozen statistics (fine-tuning; also what makes N ranks x B/N images equal one rank
+        x B images exactly): every batch norm normalises with its RUNNING mean and variance,
+        which no longer move, and backward treats them as constants.  gamma and beta still
+        train.  The per-layer rows (mean, rstd, scale, shift) are refreshed from the current
+        parameters at the start of every forward pass, all layers in one launch."""
+        self.freeze_bn = bool(on)
+
+    def _refresh_frozen_rows(self) -> None:
+        if self._freeze_plan is None:
+            plan = pnn.BnFoldPlan(self.device)
+            for c in self.convs:
+                if c.bn:
+                    r = self.bn_rows[c.name]
+                    plan.add(self._gamma(c), self._beta(c), self.bn_mean[c.name],
+                             self.bn_var[c.name], r[2], r[3], mean=r[0], rstd=r[1])
+            self._freeze_plan = plan
+        self._freeze_plan.run(BN_EPS)
 
     def broadcast_parameters(self, src: int = 0) -> None:
         import torch.distributed as dist
@@ -139,6 +164,9 @@ class TrainablePoseResNet(PoseResNet):
         """Normalises z with the batch statistics its conv left in the workspace as `rows`
         partial rows.  The workspace is shared, so this must run before the next conv."""
         C = z.shape[3]
+        if self.freeze_bn:     # rows hold the running statistics (see _refresh_frozen_rows)
+            r = self.bn_rows[c.name]
+            return pnn.bn_apply(z, r[2], r[3], residual, relu)
         _, _, scale, shift = pnn.bn_finalize(self._ws, rows, z.numel() // C, C, self._gamma(c),
                                              self._beta(c), BN_EPS, self.bn_momentum,
                                              self.bn_mean[c.name], self.bn_var[c.name],
@@ -224,6 +252,8 @@ class TrainablePoseResNet(PoseResNet):
         stem, blocks, deconvs, final = self.specs
         sv: dict = {"blocks": [], "deconvs": []}
         xs = x_s2d if x_s2d is not None else pnn.preprocess_u8(images_u8)
+        if self.freeze_bn:
+            self._refresh_frozen_rows()
         z0, rows = pnn.stem7x7s2_bnstats(xs, self.w(stem),
                                          self._workspace_for(xs.numel() // 16, stem.cout))
         a0 = self._bn(stem, z0, rows)
@@ -252,7 +282,7 @@ class TrainablePoseResNet(PoseResNet):
                           self._g(c.name + ".bn.gamma"), self._g(c.name + ".bn.beta"),
                           self._workspace(z), want_masked,
                           act_scale=buf[2] if rebuild else None,
-                          act_shift=buf[3] if rebuild else None)
+                          act_shift=buf[3] if rebuild else None, frozen=self.freeze_bn)
 
     def _bwd_data_bn(self, below: ConvSpec, z_below: torch.Tensor, dy: torch.Tensor,
                      wt: torch.Tensor, k: int, stride: int, pad: int) -> torch.Tensor:
@@ -266,7 +296,8 @@ class TrainablePoseResNet(PoseResNet):
                                              z_below, buf[2], buf[3], ws)
         return pnn.bn_bwd_from_partials(g, z_below, rows, self._gamma(below), buf[0], buf[1],
                                         self._g(below.name + ".bn.gamma"),
-                                        self._g(below.name + ".bn.beta"), ws)
+                                        self._g(below.name + ".bn.beta"), ws,
+                                        frozen=self.freeze_bn)
 
     def _deconv_bwd_data_bn(self, below: ConvSpec, z_below: torch.Tensor, dy: torch.Tensor,
                             wt: torch.Tensor) -> torch.Tensor:
@@ -275,7 +306,8 @@ class TrainablePoseResNet(PoseResNet):
         g, rows = pnn.deconv4x4s2_bwd_data_bnmask(dy, wt, z_below, buf[2], buf[3], ws)
         return pnn.bn_bwd_from_partials(g, z_below, rows, self._gamma(below), buf[0], buf[1],
                                         self._g(below.name + ".bn.gamma"),
-                                        self._g(below.name + ".bn.beta"), ws)
+                                        self._g(below.name + ".bn.beta"), ws,
+                                        frozen=self.freeze_bn)
 
     def _done(self, c: ConvSpec) -> None:
         if self.bucketer is not None:

@@ -113,3 +113,31 @@ def test_trainer_resizes_and_augments_raw_frames():
     a.build_model(seed=5)
     b.build_model(seed=5)
     assert a.train_step(frames, joints).item() == b.train_step(frames, joints).item()
+
+
+@pytest.mark.gpu
+def test_notebook_flow_with_the_reference_augmentation_config():
+    """Trainer(cfg).get_features_labels_data() -> train_step(features, labels) with the
+    reference's own train_config (flip, crop, scale jitter: test.ipynb:995-997): the generator
+    leaves the ignore mask out, because a mask is tied to the frame it was drawn on."""
+    cfg = {"train_config": {"batch_size": 4, "preprocess": {"image_resize": [64, 96]},
+                            "augmentation": {"flip_left_right": True, "random_crop": True,
+                                             "scale_range": [0.5, 2.0]}},
+           "model_config": {"layers": [1, 1, 1, 1]}}
+    tr = pe.Trainer(cfg)
+    tr.build_model(seed=5)
+    losses = []
+    for features, labels in tr.get_features_labels_data(num_batches=3):
+        assert "masks" not in labels and labels["heatmaps"].shape == (4, 16, 24, 17)
+        losses.append(tr.train_step(features, labels).item())
+    assert all(np.isfinite(losses))
+    # predict folds the constants once per parameter change, not on every call
+    f0 = tr.net.scale["stem"].clone()
+    tr.predict(features["images"])
+    folded = tr.net.scale["stem"].clone()
+    tr.net.scale["stem"].fill_(7.0)      # a second predict must not fold again ...
+    tr.predict(features["images"])
+    assert torch.all(tr.net.scale["stem"] == 7.0)
+    tr.train_step(features, labels)      # ... until a step has moved the parameters
+    tr.predict(features["images"])
+    assert not torch.all(tr.net.scale["stem"] == 7.0) and f0.shape == folded.shape

@@ -1,0 +1,80 @@
+"""The data-parallel training path with TWO ranks (the reference trains under Horovod,
+test.ipynb:12).  A one-GPU box cannot hold two RCCL ranks, so both ranks share cuda:0 and the
+collectives go through gloo; everything else -- buckets announced from the weight-gradient
+stream as backward finishes them, out-of-order layer completion in the branched graphs, the
+exchange running behind an event beside backward, finish() before the optimizer -- is the code
+RCCL runs.  tests/rehearse_dp.py is started in a fresh interpreter whose parent process never
+touches the GPU and spawns the two ranks itself."""
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _run(*args):
+    r = subprocess.run([sys.executable, "-u", str(ROOT / "tests" / "rehearse_dp.py"), *args],
+                       capture_output=True, text=True, timeout=280, cwd=str(ROOT))
+    out = r.stdout + r.stderr
+    assert r.returncode == 0, out[-4000:]
+    assert "rehearsal ok" in r.stdout, out[-4000:]
+    return r.stdout
+
+
+@pytest.mark.parametrize("which", ["resnet", "hrnet", "mobilenet"])
+def test_two_ranks_sum_gradients_and_stay_identical(which):
+    out = _run(which, "rehearse", "f32")
+    assert out.count("parameters identical on both ranks") == 2
+
+
+def test_two_ranks_with_bf16_gradient_transport():
+    out = _run("resnet", "rehearse", "bf16")
+    assert out.count("parameters identical on both ranks") == 2
+
+
+@pytest.mark.parametrize("which", ["resnet", "hrnet"])
+def test_two_half_batches_equal_one_full_batch_with_frozen_batch_norm(which):
+    out = _run(which, "equiv", "f32")
+    assert out.count("images vs 1 x 8") == 2
+
+
+def test_bucketer_over_the_native_communicator_single_rank():
+    """GradBucketer driven by the library's own RCCL communicator (pe_allreduce_bucket on a
+    stream of its own, ordered by events): with one rank the exchanged arena equals the local
+    one, float32 exactly and bf16 transport to one rounding; the pre-multiplied scale of
+    pe_allreduce_bucket is applied for both dtypes."""
+    from pose_estimation_amd.parallel import GradBucketer, NativeComm
+
+    torch.cuda.set_device(0)
+    comm = NativeComm(0, 1, NativeComm.unique_id())
+    g = torch.Generator().manual_seed(5)
+    bounds = [0, 64, 640, 1000, 3000, 4096]
+    for transport in ("f32", "bf16"):
+        arena = torch.randn(5000, generator=g).cuda()
+        want = arena.clone() if transport == "f32" else arena.to(torch.bfloat16).float()
+        bk = GradBucketer(arena, bounds, bucket_bytes=4 * 700, comm=comm, transport=transport)
+        assert bk.world == 1 and bk.backend == "native" and len(bk.buckets) >= 3
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):          # announced from another stream, as backward does
+            side.wait_stream(torch.cuda.default_stream())
+            for s in reversed(bounds):
+                bk.layer_done(s)
+        torch.cuda.current_stream().wait_stream(side)
+        bk.finish()
+        torch.cuda.synchronize()
+        assert torch.equal(arena, want), transport
+    a = torch.randn(4099, generator=g).cuda()
+    b = a.to(torch.bfloat16)
+    comm.all_reduce_(a.clone(), scale=1.0)
+    wa = a * 0.25
+    comm.all_reduce_(a, scale=0.25)
+    wb = (b.float() * 0.25).to(torch.bfloat16)
+    comm.all_reduce_(b, scale=0.25)
+    torch.cuda.synchronize()
+    assert torch.equal(a, wa) and torch.equal(b, wb)
+    comm.close()
