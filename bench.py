@@ -1,12 +1,15 @@
 #!/usr/bin/env python3
 """Benchmark of the pose-estimation hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W [--workload decode|render|mse|mse_fused|adam]
+    python bench.py --gpus N --steps K --warmup W [--workload decode|render|mse|...]
 
-N > 1 is launched by torch.distributed.run (one rank per GPU).  Every workload here shards by
-batch with no data-path collective, so each rank processes its own batch of the stated size
-(weak scaling); the only collectives are the barriers and the max-over-ranks of the timing.
-Rank 0 prints ONE JSON line.
+One process per GPU.  Under torch.distributed.run (RANK / WORLD_SIZE in the environment) this
+process is one rank.  Started plainly with --gpus N > 1 it launches the N ranks itself, as child
+processes of a parent that never touches a GPU, and exits non-zero if fewer than N GPUs are
+visible: the line printed always reports the number of ranks that really ran.
+Every workload shards by batch (weak scaling: each rank processes its own batch of the stated
+size); the training workloads exchange gradients (bucketed all-reduce over RCCL), the others
+use no data-path collective.  Rank 0 prints ONE JSON line.
 
 Default workload "decode" is BASELINE.json configs[1]: heat-map peak decode of
 1024 x 17 x 64 x 48 float32 maps per step, inputs resident in HBM, rotating over enough
@@ -37,6 +40,18 @@ K_JOINTS, H, W = 17, 64, 48
 MAP_BYTES = H * W * 4
 
 
+def host_cores() -> int:
+    """Host threads the CPU baselines use: the box's CPU share (OMP_NUM_THREADS where the
+    harness sets it; os.cpu_count() reports the whole machine there), else every core."""
+    n = os.environ.get("OMP_NUM_THREADS")
+    if n and n.isdigit() and int(n) > 0:
+        return int(n)
+    try:
+        return len(os.sched_getaffinity(0))
+    except AttributeError:
+        return os.cpu_count() or 1
+
+
 class Workload:
     name = ""
     batch = 0
@@ -60,13 +75,12 @@ class Decode(Workload):
     nbuf = 4  # 4 x 214 MB = 856 MB of distinct inputs
 
     def setup(self, device):
-        g = torch.Generator(device=device).manual_seed(1234 + device.index)
-        self.bufs = []
-        for _ in range(self.nbuf):
-            hm = torch.randn(self.batch, K_JOINTS, H, W, device=device, generator=g) * 0.01
-            pos = torch.randint(0, H * W, (self.batch, K_JOINTS), device=device, generator=g)
-            hm.view(self.batch, K_JOINTS, -1).scatter_(2, pos[..., None], 0.8)
-            self.bufs.append(hm)
+        # the stated generator: per map one Gaussian blob (sigma 2, amplitude U(0.3, 1)) at a
+        # uniformly random sub-pixel centre plus N(0, 0.01) noise, NumPy PCG64, one seed per buffer
+        rank = int(os.environ.get("RANK", "0"))
+        self.bufs = [torch.from_numpy(synthetic.decode_heatmaps(self.batch, K_JOINTS, H, W,
+                                                                seed=100 * rank + i)).to(device)
+                     for i in range(self.nbuf)]
         self.out = (torch.empty(self.batch, K_JOINTS, 2, device=device),
                     torch.empty(self.batch, K_JOINTS, device=device),
                     torch.empty(self.batch, K_JOINTS, dtype=torch.int32, device=device))
@@ -75,20 +89,28 @@ class Decode(Workload):
         pe.decode(self.bufs[i % self.nbuf], refine=True, out=self.out)
 
     def cpu_baseline(self):
+        from concurrent.futures import ThreadPoolExecutor
+
         import oracle
 
+        cores = host_cores()
         hm = synthetic.decode_heatmaps(self.batch, K_JOINTS, H, W, seed=0)
-        oracle.decode_heatmaps(hm[:64])
+        # the batch is cut into one slice per core (NumPy releases the GIL inside its loops)
+        cuts = np.linspace(0, self.batch, cores + 1).astype(int)
+        parts = [hm[a:b] for a, b in zip(cuts[:-1], cuts[1:]) if b > a]
         times = []
-        t_end = time.perf_counter() + 12.0
-        while len(times) < 5 or (time.perf_counter() < t_end and len(times) < 40):
-            t0 = time.perf_counter()
-            oracle.decode_heatmaps(hm)
-            times.append(time.perf_counter() - t0)
+        with ThreadPoolExecutor(max_workers=cores) as ex:
+            list(ex.map(oracle.decode_heatmaps, parts))
+            t_end = time.perf_counter() + 10.0
+            while len(times) < 5 or (time.perf_counter() < t_end and len(times) < 40):
+                t0 = time.perf_counter()
+                list(ex.map(oracle.decode_heatmaps, parts))
+                times.append(time.perf_counter() - t0)
         med = float(np.median(times))
-        return {"value": self.batch / med, "unit": "images/s", "cores": 1, "kind": "port",
-                "sample": f"NumPy oracle, full {self.batch}x{K_JOINTS}x{H}x{W} batch, "
-                          f"median of {len(times)} runs ({med * 1e3:.1f} ms each)"}
+        return {"value": self.batch / med, "unit": "images/s", "cores": cores, "kind": "port",
+                "sample": f"NumPy oracle, full {self.batch}x{K_JOINTS}x{H}x{W} batch in "
+                          f"{len(parts)} slices on {cores} threads, median of {len(times)} runs "
+                          f"({med * 1e3:.1f} ms each)"}
 
 
 class Render(Workload):
@@ -328,16 +350,24 @@ class Infer(Workload):
         specs = model.resnet50_pose_specs()
         state = model.init_state(specs, seed=3)
         img = synthetic.images_u8(8, 256, 192, seed=1)
+        import oracle
+
+        def once():
+            hm = to.pose_resnet_forward(specs, state, img, pnn.IMAGENET_MEAN, pnn.IMAGENET_STD)
+            oracle.decode_heatmaps(np.asarray(hm, dtype=np.float32))
+
         to.pose_resnet_forward(specs, state, img[:1], pnn.IMAGENET_MEAN, pnn.IMAGENET_STD)
         times = []
-        for _ in range(3):
+        t_end = time.perf_counter() + 10.0
+        while len(times) < 3 or (time.perf_counter() < t_end and len(times) < 100):
             t0 = time.perf_counter()
-            to.pose_resnet_forward(specs, state, img, pnn.IMAGENET_MEAN, pnn.IMAGENET_STD)
+            once()
             times.append(time.perf_counter() - t0)
         med = float(np.median(times))
         return {"value": 8 / med, "unit": "images/s", "cores": torch.get_num_threads(),
                 "kind": "port",
-                "sample": f"torch-CPU float32 oracle forward, batch 8, median of 3 ({med:.2f} s)"}
+                "sample": f"torch-CPU float32 oracle forward + NumPy decode, batch 8, median of "
+                          f"{len(times)} runs ({med:.2f} s each)"}
 
 
 class MobileNetInfer(Workload):
@@ -486,15 +516,19 @@ class Train(Workload):
         img = synthetic.images_u8(B, 256, 192, seed=1)
         j = synthetic.joints(B, K_JOINTS, 256, 192, seed=2)
         m = synthetic.ignore_mask(B, H, W, seed=4)
-        t0 = time.perf_counter()
-        t, w = oracle.render_targets(j, H, W, 4.0, 2.0, 6)
-        to.pose_resnet_train_reference(specs, state, img, t, w, m, pnn.IMAGENET_MEAN,
-                                       pnn.IMAGENET_STD)
-        dt = time.perf_counter() - t0
+        times = []
+        t_end = time.perf_counter() + 12.0
+        while len(times) < 2 or (time.perf_counter() < t_end and len(times) < 50):
+            t0 = time.perf_counter()
+            t, w = oracle.render_targets(j, H, W, 4.0, 2.0, 6)
+            to.pose_resnet_train_reference(specs, state, img, t, w, m, pnn.IMAGENET_MEAN,
+                                           pnn.IMAGENET_STD)
+            times.append(time.perf_counter() - t0)
+        dt = float(np.median(times))
         return {"value": B / dt, "unit": "images/s", "cores": torch.get_num_threads(),
                 "kind": "port",
                 "sample": f"torch-CPU autograd oracle (render + loss + backward, no optimizer), "
-                          f"batch {B}, one run ({dt:.1f} s)"}
+                          f"batch {B}, median of {len(times)} runs ({dt:.2f} s each)"}
 
 
 class HRNetTrain(Workload):
@@ -685,6 +719,35 @@ WORKLOADS = {"decode": Decode, "render": Render, "mse": Mse, "mse_fused": MseFus
              "mobilenet_train": MobileNetTrain, "mobilenet_det_train": MobileNetDetTrain}
 
 
+def launch_ranks(args) -> int:
+    """--gpus N > 1 without a launcher: start the N ranks as child processes.  This parent makes
+    no GPU call (torch.cuda.device_count() does not initialise the GPU), so the children are
+    fresh processes and nothing that has touched a GPU is ever re-executed."""
+    import socket
+    import subprocess
+
+    rehearse = os.environ.get("PE_REHEARSE_ON_ONE_GPU") == "1"
+    ndev = torch.cuda.device_count()
+    if ndev < args.gpus and not rehearse:
+        print(f"bench.py: --gpus {args.gpus} but only {ndev} GPU(s) are visible "
+              "(PE_REHEARSE_ON_ONE_GPU=1 rehearses N ranks on one GPU over gloo)", file=sys.stderr)
+        return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus),
+                   LOCAL_WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve()),
+                                       *sys.argv[1:]], env=env))
+    rc = 0
+    for pr in procs:
+        rc = max(rc, abs(pr.wait()))
+    return rc
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -697,16 +760,24 @@ def main() -> None:
     ap.add_argument("--also-timeout", type=float, default=240.0)
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be at least 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the line would misreport "
+                         "the number of GPUs")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback for the measured path)")
     # PE_REHEARSE_ON_ONE_GPU=1: every rank uses cuda:0 and the collectives go through gloo, so
     # the N > 1 code path can be rehearsed on a one-GPU box (RCCL refuses two ranks per device).
     rehearse = os.environ.get("PE_REHEARSE_ON_ONE_GPU") == "1"
+    if not rehearse and torch.cuda.device_count() <= local_rank:
+        raise SystemExit(f"rank {rank}: local rank {local_rank} has no GPU "
+                         f"({torch.cuda.device_count()} visible)")
     device = torch.device("cuda", 0 if rehearse else local_rank)
     torch.cuda.set_device(device)
     dist = None
@@ -717,27 +788,37 @@ def main() -> None:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=device)
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit(f"process group has {dist.get_world_size()} ranks, --gpus {args.gpus}")
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize(device)
 
+    progress = {"leg": args.workload, "phase": "setup", "step": -1}
+
     def measure(wl, steps, warmup):
         """W untimed steps, then exactly K steps between barrier + synchronize on both sides;
         (wall seconds, device milliseconds between HIP events on the launch stream), each the
         maximum over ranks."""
+        progress.update(phase="setup", step=-1)
         wl.setup(device)
+        progress.update(phase="warmup")
         for i in range(warmup):
+            progress["step"] = i
             wl.step(i)
         barrier()
+        progress.update(phase="timed")
         ev0 = torch.cuda.Event(enable_timing=True)
         ev1 = torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
         ev0.record()
         for i in range(steps):
+            progress["step"] = i
             wl.step(i)
         ev1.record()
+        progress.update(phase="barrier")
         barrier()
         elapsed = time.perf_counter() - t0
         dev_ms = ev0.elapsed_time(ev1)  # same stream as the launches (torch's current stream)
@@ -748,14 +829,24 @@ def main() -> None:
             elapsed, dev_ms = float(t[0]), float(t[1])
         return elapsed, dev_ms
 
+    traffic_file = ROOT / "profiles" / "traffic.json"
+    traffic = json.loads(traffic_file.read_text()) if traffic_file.exists() else {}
+
     def roofline_of(wl, kern_ms):
         if hasattr(wl, "roofline"):
-            return wl.roofline(kern_ms)
-        achieved = wl.bytes_per_step / (kern_ms * 1e-3) / 1e9
-        return {"bound": wl.bound, "kernel": wl.kernel, "achieved": achieved,
-                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                "bytes_per_launch": wl.bytes_per_step, "launch_ms": kern_ms,
-                "traffic": None}
+            rl = wl.roofline(kern_ms)
+        else:
+            achieved = wl.bytes_per_step / (kern_ms * 1e-3) / 1e9
+            rl = {"bound": wl.bound, "kernel": wl.kernel, "achieved": achieved,
+                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                  "bytes_per_launch": wl.bytes_per_step, "launch_ms": kern_ms, "traffic": None}
+        # HBM bytes per launch (per step for the network workloads) from the committed
+        # rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, gfx950-corrected); null when this
+        # workload has not been profiled
+        rec = traffic.get(wl.name)
+        if rec:
+            rl["traffic"] = rec["traffic_bytes_per_launch"]
+        return rl
 
     wl = WORKLOADS[args.workload]()
     elapsed, dev_ms = measure(wl, args.steps, args.warmup)
@@ -766,6 +857,8 @@ def main() -> None:
             "value": world * wl.batch * args.steps / elapsed,
             "unit": "images/s" if args.workload != "adam" else "steps/s",
             "n_gpus": world,
+            "ranks": dist.get_world_size() if dist is not None else 1,
+            "collective_backend": (dist.get_backend() if dist is not None else None),
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed * 1e3 / args.steps,
@@ -779,22 +872,15 @@ def main() -> None:
                        "sharding": getattr(wl, "sharding", "batch, no collective")},
             "roofline": roofline_of(wl, dev_ms / args.steps),
         }
-        # HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE,
-        # gfx950-corrected); null when this workload has not been profiled.
-        tfile = ROOT / "profiles" / "traffic.json"
-        if tfile.exists():
-            rec = json.loads(tfile.read_text()).get(wl.name)
-            if rec:
-                out["roofline"]["traffic"] = rec["traffic_bytes_per_launch"]
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = wl.cpu_baseline()
 
     # The metric also names network inference and the data-parallel training step.  A default
     # run measures them after the headline workload, with the same barrier-bracketed loop, and
     # reports them under "also" in the same JSON line (whole-job images/s over all ranks), so a
     # 1/2/4/8-GPU sweep of this script shows how the training step's gradient all-reduce scales.
     # They never change "value".  A failure or a stall in them must not lose the headline
-    # number: errors are recorded, and a watchdog prints the line and ends the process.
+    # number: errors are recorded in the line; a watchdog prints the line, says which leg and
+    # step were in flight, and ends the process with a non-zero status.
+    legs = []
     if args.workload == "decode" and not args.no_also:
         import threading
 
@@ -803,18 +889,24 @@ def main() -> None:
             out["also"] = also
 
         def give_up():
+            msg = (f"secondary workloads exceeded {args.also_timeout} s in leg "
+                   f"{progress['leg']!r}, phase {progress['phase']!r}, step {progress['step']}")
             if out is not None:
-                also.setdefault("error", f"secondary workloads exceeded {args.also_timeout} s")
+                also.setdefault("error", msg)
                 print(json.dumps(out), flush=True)
-            os._exit(0)
+            print(f"bench.py rank {rank}: {msg}", file=sys.stderr, flush=True)
+            os._exit(3)
 
         dog = threading.Timer(args.also_timeout, give_up)
         dog.daemon = True
         dog.start()
+        first = wl
         wl = None
-        torch.cuda.empty_cache()
         steps2, warm2 = max(1, min(args.steps, 50)), max(1, min(args.warmup, 10))
+        failed = False
         for key in ("infer", "train"):
+            progress.update(leg=key)
+            torch.cuda.empty_cache()
             try:
                 w2 = WORKLOADS[key]()
                 e2, d2 = measure(w2, steps2, warm2)
@@ -825,13 +917,29 @@ def main() -> None:
                                         "sharding": getattr(w2, "sharding",
                                                             "batch, no collective")},
                              "roofline": roofline_of(w2, d2 / steps2)}
+                legs.append((key, w2))
             except Exception as exc:  # noqa: BLE001 - recorded in the line, headline kept
                 also[key] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
+                failed = True
                 break   # the ranks may no longer be in step: no further collectives
             finally:
                 w2 = None
-                torch.cuda.empty_cache()
         dog.cancel()
+        wl = first
+        if failed and dist is not None:
+            if out is not None:
+                print(json.dumps(out), flush=True)
+            os._exit(4)   # ranks out of step: no barrier can be trusted any more
+
+    # CPU baselines (rank 0 of a one-GPU run only): the oracle of each measured leg timed on the
+    # host cores, a bounded sample each; GPU work is over, so they do not disturb the timings
+    if out is not None and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = wl.cpu_baseline()
+        for key, w2 in legs:
+            try:
+                out["also"][key]["cpu_baseline"] = w2.cpu_baseline()
+            except Exception as exc:  # noqa: BLE001
+                out["also"][key]["cpu_baseline"] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
 
     if out is not None:
         print(json.dumps(out), flush=True)

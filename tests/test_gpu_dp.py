@@ -78,3 +78,37 @@ def test_bucketer_over_the_native_communicator_single_rank():
     torch.cuda.synchronize()
     assert torch.equal(a, wa) and torch.equal(b, wb)
     comm.close()
+
+
+def _bench(*args, env=None):
+    import os
+
+    e = dict(os.environ)
+    e.pop("WORLD_SIZE", None)
+    e.pop("RANK", None)
+    e.update(env or {})
+    return subprocess.run([sys.executable, "-u", str(ROOT / "bench.py"), *args], env=e,
+                          capture_output=True, text=True, timeout=280, cwd=str(ROOT))
+
+
+def test_bench_launches_its_own_ranks_and_refuses_to_misreport():
+    """`bench.py --gpus 2` started plainly spawns two ranks itself.  On a one-GPU box that is an
+    error (exit status 2, no JSON line); with the rehearsal switch the two ranks share the GPU,
+    run the data-parallel training step and report two ranks."""
+    import json
+
+    if torch.cuda.device_count() < 2:
+        r = _bench("--gpus", "2", "--steps", "2", "--warmup", "1")
+        assert r.returncode == 2 and "only 1 GPU" in r.stderr and "{" not in r.stdout
+    r = _bench("--gpus", "2", "--workload", "train", "--steps", "2", "--warmup", "1",
+               "--no-cpu-baseline", env={"PE_REHEARSE_ON_ONE_GPU": "1"})
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1                      # rank 0 alone prints
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["ranks"] == 2 and rec["collective_backend"] == "gloo"
+    assert rec["config"]["workload"].startswith("resnet50_pose_train") and rec["value"] > 0
+    # a launcher's world size that contradicts --gpus is refused too
+    r = _bench("--gpus", "1", "--steps", "1", "--warmup", "0", "--no-also", "--no-cpu-baseline",
+               env={"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and "WORLD_SIZE=2" in r.stderr

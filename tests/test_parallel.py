@@ -124,3 +124,20 @@ def test_native_rccl_communicator_single_rank():
     torch.cuda.synchronize()
     assert torch.equal(a, want) and torch.equal(b, wantb)
     comm.close()
+
+
+def test_bench_refuses_more_ranks_than_gpus():
+    """Without N visible GPUs `bench.py --gpus N` exits non-zero and prints no result line (here:
+    no GPU at all, or one)."""
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 8:
+        pytest.skip("eight GPUs are visible")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK",
+                                                           "PE_REHEARSE_ON_ONE_GPU")}
+    root = Path(__file__).resolve().parent.parent
+    r = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "8"], env=env,
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode == 2 and "--gpus 8" in r.stderr and "{" not in r.stdout
