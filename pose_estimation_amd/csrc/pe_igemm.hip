@@ -1,14 +1,18 @@
 // Implicit-GEMM convolution kernel: bf16 MFMA 16x16x32, fp32 accumulate, direct-to-LDS tiles.
 //
-// Workgroup = WM x 2 waves (WM = 2 or 4 along pixels, 2 along channels), output tile BM pixels
-// x BN channels, K step 64; every wave owns a (BM/WM) x (BN/2) sub-tile.  Tiles go global -> LDS
+// Workgroup = WM x WN waves (WM = 2 or 4 along pixels, WN = 2 or 4 along channels), output tile
+// BM pixels x BN channels, K step 64; every wave owns a (BM/WM) x (BN/WN) sub-tile.  Tiles go global -> LDS
 // with global_load_lds_dwordx4 (16 B per lane, no VGPR staging, no ds_write pass) into 128-byte
-// rows.  Two pipelines exist:
-//   single buffer : load, barrier, MFMA, barrier; <= 35 KB of LDS and 128 VGPRs, so four
+// rows.  Three pipelines exist (template parameter PIPE):
+//   0, single buffer : load, barrier, MFMA, barrier; <= 35 KB of LDS and 128 VGPRs, so four
 //                   256-thread workgroups share a CU and cover each other's load latency;
-//   double buffer : the loads of K step k+1 are in flight while step k is multiplied, one
-//                   barrier per step; the workgroup hides its own latency, which is what lets
-//                   256-pixel tiles (fewer L2 -> LDS bytes per flop) run with 1-2 workgroups per CU.
+//   1, double buffer : the loads of K step k+1 are in flight while step k is multiplied, one
+//                   __syncthreads per step (which drains every outstanding load);
+//   N >= 2, ring   : N LDS stages, the loads of K steps k+1 .. k+N-1 in flight while step k is
+//                   multiplied.  One raw s_barrier per step and a COUNTED s_waitcnt vmcnt that
+//                   retires only step k's loads, so younger tiles stay in flight across the
+//                   barrier and the workgroup hides its own load latency: what large tiles
+//                   (256 pixels, eight waves, one workgroup per CU) need.
 //
 // A wave instruction writes 1 KiB = 8 consecutive LDS rows, lane l to (row l>>3, 16-byte slot
 // l&7).  Rows are unpadded, so bank conflicts are avoided by an XOR swizzle: slot s of row r holds
@@ -56,26 +60,43 @@ __device__ __forceinline__ void fast_divmod(int m, int d, float inv_d, int& q, i
     r -= fix * d;
 }
 
-template <int BM, int BN, int WM, bool DB, bool PF, int MINB, bool MASK = false>
-__global__ __launch_bounds__(WM * 128, MINB)
-__attribute__((amdgpu_waves_per_eu(MINB * WM / 2, MINB * WM / 2))) void igemm_kernel(const IgemmParams p) {
+// s_waitcnt vmcnt(N): all but this wave's N youngest vector-memory operations are done.
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    static_assert(N >= 0 && N <= 63, "vmcnt immediate out of range");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// FAST: addresses of the staging loads cost a 64-bit add and a select instead of a multiply
+// chain: every tile row keeps the pointer of its centre pixel and one bit per tap ("this tap
+// lies inside the image"), and a K step adds a wave-uniform byte offset.  Needs single-pixel K
+// runs, Cin a multiple of 64 and at most 32 taps per phase (igemm_launch checks).
+template <int BM, int BN, int WM, int PIPE, bool PF, int MINB, bool MASK = false, int WN = 2,
+          bool FAST = false>
+__global__ __launch_bounds__(WM * WN * 64, MINB)
+__attribute__((amdgpu_waves_per_eu(MINB * WM * WN / 4, MINB * WM * WN / 4))) void igemm_kernel(const IgemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int NT = WM * 128;      // threads
+    constexpr bool DB = PIPE == 1;    // the double buffer with draining barriers
+    constexpr int NS = PIPE >= 2 ? PIPE : 0;   // ring stages
+    constexpr int NT = WM * WN * 64;  // threads
     constexpr int RPI = NT / 8;       // tile rows one staging instruction of the workgroup covers
     constexpr int WROWS = BM / WM;    // pixels per wave
+    constexpr int WCOLS = BN / WN;    // channels per wave
     constexpr int TM = WROWS / 16;    // 16-pixel tiles per wave
-    constexpr int TN = BN / 32;       // 16-channel tiles per wave (wave covers BN/2 channels)
+    constexpr int TN = WCOLS / 16;    // 16-channel tiles per wave
     constexpr int XI = BM / RPI;      // activation rows staged per thread
     constexpr int WI = BN / RPI;      // weight rows staged per thread
     constexpr int XBYTES = BM * ROWB;
     constexpr int TILEB = (BM + BN) * ROWB;
-    static_assert(XI >= 1 && WI >= 1 && TM >= 1, "tile too small for the workgroup");
+    static_assert(XI >= 1 && WI >= 1 && TM >= 1 && TN >= 1, "tile too small for the workgroup");
+    static_assert(WM % 2 == 0, "the epilogue stages the tile in two halves of the wave rows");
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wid = tid >> 6;
-    const int wave_m = wid >> 1;
-    const int wave_n = wid & 1;
+    // the wave index as a scalar: LDS destinations of the staging loads (M0) stay in SGPRs
+    const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_m = wid / WN;
+    const int wave_n = wid % WN;
 
     // ---- phase (uniform)
     const int ph = blockIdx.y;
@@ -142,7 +163,38 @@ __attribute__((amdgpu_waves_per_eu(MINB * WM / 2, MINB * WM / 2))) void igemm_ke
     const int lr = lane & 15;
     const int sw = lane & 7;  // (row & 7) of every fragment row this lane reads
     const int xs_off = (wave_m * WROWS + lr) * ROWB;
-    const int ws_off = XBYTES + (wave_n * (BN / 2) + lr) * ROWB;
+    const int ws_off = XBYTES + (wave_n * WCOLS + lr) * ROWB;
+
+    // FAST addressing state (see the template comment)
+    const char* xrow[FAST ? XI : 1];
+    uint32_t xmask[FAST ? XI : 1];
+    const char* wrow[FAST ? WI : 1];
+    if constexpr (FAST) {
+#pragma unroll
+        for (int i = 0; i < XI; ++i) {
+            xrow[i] = reinterpret_cast<const char*>(
+                p.x + ((long)(pixbase[i] + iy0[i] * p.Wi + ix0[i]) * p.Cx + cc * 8));
+            xmask[i] = 0u;
+        }
+        for (int t = 0; t < T; ++t) {
+            const int inf = p.tap_info[(t0 + t) & (kMaxTaps - 1)];
+            const int dy = (int)(int8_t)(inf & 0xff);
+            const int dx = (int)(int8_t)((inf >> 8) & 0xff);
+#pragma unroll
+            for (int i = 0; i < XI; ++i) {
+                const bool ok = (unsigned)(iy0[i] + dy) < (unsigned)p.Hi &&
+                                (unsigned)(ix0[i] + dx) < (unsigned)p.Wi;
+                xmask[i] |= ok ? (1u << t) : 0u;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < WI; ++i) {
+            // channels past N read the last real row: their products are never stored
+            int n = n0 + r0 + RPI * i;
+            n = n < p.N ? n : p.N - 1;
+            wrow[i] = reinterpret_cast<const char*>(wbase + ((long)n * ktot + cc * 8));
+        }
+    }
 
     int tap = t0, cstep = 0;
     // (dy, dx, weight slot) of the current tap, one dword from the kernel arguments (a scalar
@@ -152,6 +204,30 @@ __attribute__((amdgpu_waves_per_eu(MINB * WM / 2, MINB * WM / 2))) void igemm_ke
     auto issue = [&](char* dst) {
         const int dy = (int)(int8_t)(info & 0xff);
         const int dx = (int)(int8_t)((info >> 8) & 0xff);
+        if constexpr (FAST) {
+            // wave-uniform byte offsets of this K step
+            const long xoff = ((long)(dy * p.Wi + dx) * p.Cx + cstep * BK) * 2;
+            const long woff = ((long)(info >> 16) * p.Cin + cstep * BK) * 2;
+            const uint32_t bit = 1u << (tap - t0);
+#pragma unroll
+            for (int i = 0; i < XI; ++i) {
+                const char* src = (xmask[i] & bit) ? xrow[i] + xoff
+                                                   : reinterpret_cast<const char*>(zero);
+                __builtin_amdgcn_global_load_lds(
+                    (gptr_t)src, (lptr_t)(dst + (RPI * i + 8 * wid) * ROWB), 16, 0, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < WI; ++i)
+                __builtin_amdgcn_global_load_lds(
+                    (gptr_t)(wrow[i] + woff),
+                    (lptr_t)(dst + XBYTES + (RPI * i + 8 * wid) * ROWB), 16, 0, 0);
+            if (++cstep == kc) {
+                cstep = 0;
+                ++tap;
+                info = p.tap_info[tap & (kMaxTaps - 1)];
+            }
+            return;
+        }
         const int coff = cstep * BK + cc * 8;
         const bool kin = coff < p.Cin;  // Cin % 8 == 0: a 16-byte chunk is whole or absent
         const long wk = (long)(info >> 16) * p.Cin + coff;  // K offset in a weight row
@@ -226,7 +302,35 @@ __attribute__((amdgpu_waves_per_eu(MINB * WM / 2, MINB * WM / 2))) void igemm_ke
         }
     };
 
-    if constexpr (DB) {
+    if constexpr (NS >= 2) {
+        // Ring of NS stages.  Iteration kt: (1) wait until this wave's loads of tile kt have
+        // landed, leaving the younger tiles in flight; (2) barrier: every wave's share of tile
+        // kt is in LDS and every wave has finished reading tile kt-1; (3) restage the slot tile
+        // kt-1 occupied with tile kt+NS-1; (4) multiply tile kt.  A tile is therefore read only
+        // after the wait that retires it AND a barrier, and a slot is overwritten only after a
+        // barrier that follows its last read.
+        constexpr int LPT = XI + WI;    // staging instructions per thread and tile
+        static_assert((NS - 2) * LPT <= 63, "too many loads in flight for the vmcnt field");
+#pragma unroll
+        for (int s = 0; s < NS - 1; ++s)
+            if (s < KT) issue(smem + s * TILEB);
+        int cur = 0, nxt = NS - 1;
+        for (int kt = 0; kt < KT; ++kt) {
+            // tiles issued so far: min(KT, kt + NS - 1); all but tile kt's may stay in flight
+            if (kt + NS - 1 <= KT) wait_vmcnt<(NS - 2) * LPT>();
+            else wait_vmcnt<0>();       // the last NS-2 steps: nothing younger worth keeping
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // own reads of tile kt-1 are back
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (kt + NS - 1 < KT) issue(smem + nxt * TILEB);
+            __builtin_amdgcn_s_setprio(1);
+            multiply(smem + cur * TILEB);
+            __builtin_amdgcn_s_setprio(0);
+            if (++cur == NS) cur = 0;
+            if (++nxt == NS) nxt = 0;
+        }
+        __syncthreads();   // the epilogue reuses the stages
+    } else if constexpr (DB) {
         issue(smem);
         __syncthreads();  // the compiler drains vmcnt before a barrier: tile 0 is in LDS
         for (int kt = 0; kt < KT; ++kt) {
@@ -324,7 +428,7 @@ __attribute__((amdgpu_waves_per_eu(MINB * WM / 2, MINB * WM / 2))) void igemm_ke
                 const int rbase = (wave_m % (WM / 2)) * WROWS;
 #pragma unroll
                 for (int a = 0; a < TN; ++a) {
-                    const int col = wave_n * (BN / 2) + a * 16 + nq;
+                    const int col = wave_n * WCOLS + a * 16 + nq;
                     const int nn = n0 + col;
                     if (p.scale || p.shift) {  // uniform: training convs carry neither
                         f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
@@ -482,7 +586,7 @@ __attribute__((amdgpu_waves_per_eu(MINB * WM / 2, MINB * WM / 2))) void igemm_ke
         const long opix = (long)bb * OHW + opl;
 #pragma unroll
         for (int a = 0; a < TN; ++a) {
-            const int n = n0 + wave_n * (BN / 2) + a * 16 + nq;
+            const int n = n0 + wave_n * WCOLS + a * 16 + nq;
             const float v[4] = {acc[a][b].x, acc[a][b].y, acc[a][b].z, acc[a][b].w};
             for (int j = 0; j < 4 && n + j < p.N; ++j) {
                 float t = v[j] * (p.scale ? p.scale[n + j] : 1.0f) + (p.shift ? p.shift[n + j] : 0.0f);
@@ -501,9 +605,9 @@ __attribute__((amdgpu_waves_per_eu(MINB * WM / 2, MINB * WM / 2))) void igemm_ke
     }
 }
 
-template <int BM, int BN, bool DB, int NT = 256, bool MASK = false>
+template <int BM, int BN, int PIPE, int NT = 256, bool MASK = false>
 static constexpr size_t lds_bytes() {
-    const size_t ktile = (size_t)(BM + BN) * ROWB * (DB ? 2 : 1);
+    const size_t ktile = (size_t)(BM + BN) * ROWB * (PIPE == 0 ? 1 : (PIPE == 1 ? 2 : PIPE));
     // epilogue half tile + the per-group column sums of the fused batch-norm statistics
     const size_t etile = (size_t)(BM / 2) * (BN + 4) * sizeof(float) + 2 * 512 * sizeof(float);
     const size_t mtile = MASK ? (size_t)NT * 16 * sizeof(float) : 0;  // masked sums per thread
@@ -511,7 +615,8 @@ static constexpr size_t lds_bytes() {
     return m > mtile ? m : mtile;
 }
 
-template <int BM, int BN, int WM, bool DB, bool PF, int MINB, bool MASK = false>
+template <int BM, int BN, int WM, int PIPE, bool PF, int MINB, bool MASK = false, int WN = 2,
+          bool FAST = false>
 static int32_t launch_cfg(IgemmParams& p, long maxM, hipStream_t st, const char* what) {
     const long ntm = (maxM + BM - 1) / BM;
     p.stat_ntm = (int)ntm;
@@ -523,14 +628,17 @@ static int32_t launch_cfg(IgemmParams& p, long maxM, hipStream_t st, const char*
     }
     const long ntn = (p.N + BN - 1) / BN;
     const dim3 grid((unsigned)(ntm * ntn), (unsigned)p.nphase);
-    constexpr size_t lds = lds_bytes<BM, BN, DB, WM * 128, MASK>();
+    constexpr size_t lds = lds_bytes<BM, BN, PIPE, WM * WN * 64, MASK>();
+    static_assert(lds <= 160 * 1024, "tile does not fit the CU's LDS");
     if constexpr (lds > 64 * 1024) {
         static const hipError_t once = hipFuncSetAttribute(
-            reinterpret_cast<const void*>(&igemm_kernel<BM, BN, WM, DB, PF, MINB, MASK>),
+            reinterpret_cast<const void*>(
+                &igemm_kernel<BM, BN, WM, PIPE, PF, MINB, MASK, WN, FAST>),
             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)once;
     }
-    igemm_kernel<BM, BN, WM, DB, PF, MINB, MASK><<<grid, WM * 128, lds, st>>>(p);
+    igemm_kernel<BM, BN, WM, PIPE, PF, MINB, MASK, WN, FAST>
+        <<<grid, WM * WN * 64, lds, st>>>(p);
     return check_launch(what);
 }
 
@@ -621,16 +729,46 @@ int32_t igemm_launch(const IgemmParams& pin, hipStream_t st, const char* what) {
         db = 1;
         minb = 2;
     }
-    static const char* force = getenv("PE_IGEMM_CFG");  // "BM,BN,WM,DB,PF,MINB": tuning aid
-    if (force) sscanf(force, "%d,%d,%d,%d,%d,%d", &bm, &bn, &wm, &db, &pf, &minb);
+    // cheap addressing where the layer allows it (PE_IGEMM_FAST=0: off, for comparison)
+    bool fast = p.cshift == 31 && p.Cin % BK == 0;
+    for (int i = 0; i < p.nphase; ++i) fast = fast && p.ph_T[i] <= 32;
+    {
+        static const char* fs = getenv("PE_IGEMM_FAST");
+        if (fs && atoi(fs) == 0) fast = false;
+    }
+    int wn = 2;
+    static const char* force = getenv("PE_IGEMM_CFG");  // "BM,BN,WM,PIPE,PF,MINB[,WN]": tuning aid
+    if (force) sscanf(force, "%d,%d,%d,%d,%d,%d,%d", &bm, &bn, &wm, &db, &pf, &minb, &wn);
+    // forced configurations apply only where the tile fits the layer (a 256-channel tile on a
+    // 64-channel layer would multiply padding): otherwise the automatic choice stands
+#define PE_CFG_RING(BM_, BN_, WM_, WN_, NS_, MINB_)                                        \
+    if (force && bm == BM_ && bn == BN_ && wm == WM_ && wn == WN_ && db == NS_ &&           \
+        minb == MINB_ && !p.mask_z) {                                                       \
+        if (fast)                                                                           \
+            return launch_cfg<BM_, BN_, WM_, NS_, false, MINB_, false, WN_, true>(p, maxM, st, what); \
+        return launch_cfg<BM_, BN_, WM_, NS_, false, MINB_, false, WN_>(p, maxM, st, what); \
+    }
+    PE_CFG_RING(256, 128, 4, 2, 3, 1)
+    PE_CFG_RING(256, 256, 4, 2, 2, 1)
+    PE_CFG_RING(128, 128, 2, 2, 2, 2)
+#undef PE_CFG_RING
 #define PE_CFG(BM_, BN_, WM_, DB_, PF_, MINB_)                                        \
     if (bm == BM_ && bn == BN_ && wm == WM_ && db == (DB_ ? 1 : 0) && pf == (PF_ ? 1 : 0) && \
         minb == MINB_) {                                                               \
         return launch_cfg<BM_, BN_, WM_, DB_, PF_, MINB_>(p, maxM, st, what);          \
     }
+#define PE_CFG_FAST(BM_, BN_, WM_, DB_, PF_, MINB_)                                   \
+    if (bm == BM_ && bn == BN_ && wm == WM_ && db == (DB_ ? 1 : 0) && pf == (PF_ ? 1 : 0) && \
+        minb == MINB_) {                                                               \
+        if (fast)                                                                      \
+            return launch_cfg<BM_, BN_, WM_, DB_, PF_, MINB_, false, 2, true>(p, maxM, st, what); \
+        return launch_cfg<BM_, BN_, WM_, DB_, PF_, MINB_>(p, maxM, st, what);          \
+    }
 #define PE_CFG_MASK(BM_, BN_, WM_, DB_, PF_, MINB_)                                   \
     if (p.mask_z && bm == BM_ && bn == BN_ && wm == WM_ && db == (DB_ ? 1 : 0) &&     \
         pf == (PF_ ? 1 : 0) && minb == MINB_) {                                        \
+        if (fast)                                                                      \
+            return launch_cfg<BM_, BN_, WM_, DB_, PF_, MINB_, true, 2, true>(p, maxM, st, what); \
         return launch_cfg<BM_, BN_, WM_, DB_, PF_, MINB_, true>(p, maxM, st, what);    \
     }
     PE_CFG_MASK(128, 128, 2, false, false, 4)
@@ -642,12 +780,12 @@ int32_t igemm_launch(const IgemmParams& pin, hipStream_t st, const char* what) {
     PE_CFG_MASK(64, 64, 2, true, false, 2)
 #undef PE_CFG_MASK
     PE_REQUIRE(!p.mask_z, PE_E_UNSUPPORTED, "%s: no masked kernel for tile %dx%d", what, bm, bn);
-    PE_CFG(128, 128, 2, false, false, 4)
-    PE_CFG(128, 64, 2, false, false, 4)
-    PE_CFG(64, 128, 2, false, false, 4)
-    PE_CFG(64, 64, 2, false, false, 4)
-    PE_CFG(128, 32, 2, false, false, 4)
-    PE_CFG(64, 32, 2, false, false, 4)
+    PE_CFG_FAST(128, 128, 2, false, false, 4)
+    PE_CFG_FAST(128, 64, 2, false, false, 4)
+    PE_CFG_FAST(64, 128, 2, false, false, 4)
+    PE_CFG_FAST(64, 64, 2, false, false, 4)
+    PE_CFG_FAST(128, 32, 2, false, false, 4)
+    PE_CFG_FAST(64, 32, 2, false, false, 4)
     PE_CFG(128, 128, 2, false, true, 3)
     PE_CFG(128, 128, 2, false, true, 4)
     PE_CFG(128, 128, 2, true, true, 2)
@@ -656,8 +794,8 @@ int32_t igemm_launch(const IgemmParams& pin, hipStream_t st, const char* what) {
     PE_CFG(256, 128, 4, true, true, 1)
     PE_CFG(128, 64, 2, false, true, 4)
     PE_CFG(64, 128, 2, true, false, 2)
-    PE_CFG(64, 64, 2, true, false, 2)
-    PE_CFG(64, 64, 2, false, false, 4)
+    PE_CFG_FAST(64, 64, 2, true, false, 2)
+#undef PE_CFG_FAST
 #undef PE_CFG
     PE_REQUIRE(false, PE_E_UNSUPPORTED, "%s: no kernel for tile %dx%d wm %d db %d pf %d minb %d", what, bm, bn, wm, db, pf, minb);
     return check_launch(what);
