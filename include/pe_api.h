@@ -425,6 +425,16 @@ int32_t pe_mul_f32(float* a, const float* b, int64_t n, pe_stream_t stream);
  *           frozen != 0 (pe_bn_bwd_bf16, pe_bn_bwd_from_partials_bf16): mean and rstd are the
  *           layer's running statistics, constants of the step, so dz = gamma*rstd*g; dgamma and
  *           dbeta as above.
+ *           sync (pe_bn_bwd_bf16, pe_bn_bwd_from_partials_bf16, pe_bn_finalize_apply_bf16,
+ *           pe_bn_stats_apply_bf16): DEVICE buffer of pe_bn_sync_bytes() bytes, 128-byte aligned,
+ *           prepared once with pe_bn_sync_init.  With it the per-channel finalize and the
+ *           element-wise pass are ONE launch: the first C/4 workgroups fold the partial sums and
+ *           publish the coefficients, the others wait for them inside the launch on an arrival
+ *           counter in the buffer.  The counter only grows and the library keeps its value on
+ *           the host, so calls that share a buffer must come from one host thread at a time, on
+ *           one stream, and cannot be captured into a HIP graph (a replay would repeat the old
+ *           starting value); NULL keeps the separate finalize launch.  The int32 at byte offset
+ *           2048 counts waits that timed out (such a workgroup folds for itself; never expected).
  * C must be a multiple of 8, at most 2048.  workspace: pe_bn_workspace_bytes(M, C).
  * Reductions are ordered: results are bit-stable from run to run.
  * ---------------------------------------------------------------------- */
@@ -440,7 +450,7 @@ int32_t pe_bn_bwd_bf16(const void* da, const void* a, int32_t relu, const void* 
                        const float* gamma, const float* mean, const float* rstd,
                        const float* act_scale, const float* act_shift, float* dgamma,
                        float* dbeta, void* dz, void* dmasked, void* workspace,
-                       int32_t frozen, pe_stream_t stream);
+                       int32_t frozen, int32_t* sync, pe_stream_t stream);
 
 /* Folded constants of batch-norm layers that run on their running statistics (inference, or
  * training with frozen statistics), for any number of layers in one launch:
@@ -494,7 +504,8 @@ int32_t pe_deconv4x4s2_bwd_data_bnmask_bf16(int32_t B, int32_t H, int32_t W, int
 int32_t pe_bn_bwd_from_partials_bf16(const void* g, const void* z, int32_t rows, int64_t M,
                                      int32_t C, const float* gamma, const float* mean,
                                      const float* rstd, float* dgamma, float* dbeta, void* dz,
-                                     void* workspace, int32_t frozen, pe_stream_t stream);
+                                     void* workspace, int32_t frozen, int32_t* sync,
+                                     pe_stream_t stream);
 
 /* Forward convolutions that also leave the batch-norm statistics of their own output behind,
  * so the training forward pass does not read z again to reduce it.  Same operands as
@@ -519,6 +530,22 @@ int32_t pe_stem3x3s2_fwd_bnstats_bf16(int32_t B, int32_t H2, int32_t W2, int32_t
                                       const void* x_s2d, const void* w, void* y,
                                       void* bn_workspace, size_t workspace_bytes,
                                       int32_t* rows_out, pe_stream_t stream);
+size_t pe_bn_sync_bytes(void);
+int32_t pe_bn_sync_init(int32_t* sync, pe_stream_t stream);
+/* pe_bn_finalize_bf16 followed by pe_bn_apply_bf16 on z, in one launch (see `sync` above). */
+int32_t pe_bn_finalize_apply_bf16(const void* workspace, int32_t rows, const void* z, int64_t M,
+                                  int32_t C, const float* gamma, const float* beta, float eps,
+                                  float momentum, float* running_mean, float* running_var,
+                                  float* mean, float* rstd, float* scale, float* shift,
+                                  const void* residual, int32_t relu, void* y, int32_t* sync,
+                                  pe_stream_t stream);
+/* pe_bn_stats_bf16 followed by pe_bn_apply_bf16 in two launches (reduction, then finalize +
+ * element-wise pass): for layers whose conv leaves no statistics behind (depthwise). */
+int32_t pe_bn_stats_apply_bf16(const void* z, int64_t M, int32_t C, const float* gamma,
+                               const float* beta, float eps, float momentum, float* running_mean,
+                               float* running_var, float* mean, float* rstd, float* scale,
+                               float* shift, const void* residual, int32_t relu, void* y,
+                               void* workspace, int32_t* sync, pe_stream_t stream);
 int32_t pe_bn_finalize_bf16(const void* workspace, int32_t rows, int64_t M, int32_t C,
                             const float* gamma, const float* beta, float eps, float momentum,
                             float* running_mean, float* running_var, float* mean, float* rstd,

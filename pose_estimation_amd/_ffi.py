@@ -214,12 +214,21 @@ SIGNATURES = {
                                   c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
     "pe_bn_bwd_from_partials_bf16": (
         c_int32, [c_void_p, c_void_p, c_int32, c_int64, c_int32, c_void_p, c_void_p, c_void_p,
-                  c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p]),
+                  c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p]),
     "pe_bn_bwd_bf16": (
         c_int32,
         [c_void_p, c_void_p, c_int32, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_void_p,
-         c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p],
+         c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p,
+         c_void_p],
     ),
+    "pe_bn_sync_bytes": (c_size_t, []),
+    "pe_bn_sync_init": (c_int32, [c_void_p, c_void_p]),
+    "pe_bn_stats_apply_bf16": (
+        c_int32, [c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_float, c_float]
+        + [c_void_p] * 7 + [c_int32, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "pe_bn_finalize_apply_bf16": (
+        c_int32, [c_void_p, c_int32, c_void_p, c_int64, c_int32, c_void_p, c_void_p, c_float,
+                  c_float] + [c_void_p] * 7 + [c_int32, c_void_p, c_void_p, c_void_p]),
     "pe_bn_fold_f32": (c_int32, [c_void_p, c_int32, c_float, c_void_p]),
 }
 

@@ -174,6 +174,13 @@ class TrainGraph:
         # whenever that layer's output has no other reader (PE_FUSE_BN_BWD=0: separate passes)
         self.fuse_bn_bwd = os.environ.get("PE_FUSE_BN_BWD", "1") != "0"
         self.freeze_bn = False
+        # PE_BN_FUSED=1: finalize + element-wise pass of every batch norm as ONE launch (an
+        # in-launch hand-off between workgroups; the hand-off buffer belongs to the main stream,
+        # on which all of these calls are issued).  Bit-identical results and a launch less per
+        # layer and direction, but measured no faster: the fold's latency is paid inside the
+        # launch instead of before it (ResNet-50 step 9.25 vs 8.93 ms, HRNet 37.8 vs 37.2 ms,
+        # MobileNetV2 16.13 vs 16.17 ms), so the separate finalize launch stays the default.
+        self.bn_sync = pnn.bn_sync(dev) if os.environ.get("PE_BN_FUSED", "0") == "1" else None
         # ... when the GEMM's reduction is long enough to carry the heavier epilogue: with a
         # short one (a pointwise conv from 64 channels) the separate pass measured faster
         self.fuse_min_k = int(os.environ.get("PE_FUSE_MIN_K", "256"))
@@ -325,13 +332,19 @@ class TrainGraph:
             z = pnn.depthwise3x3(x.t, self.w(L), None, None, L.stride, L.dilation, relu=0)
             M = z.numel() // L.cout
             if self.freeze_bn:
-                scale, shift = self.bn_rows[L.name][2], self.bn_rows[L.name][3]
+                r = self.bn_rows[L.name]
+                out = Var(pnn.bn_apply(z, r[2], r[3], res_t, act))
+            elif self.bn_sync is not None:
+                out = Var(pnn.bn_stats_apply(z, gamma, beta, BN_EPS, self.bn_momentum,
+                                             self.bn_mean[L.name], self.bn_var[L.name],
+                                             self._workspace_for(M, L.cout),
+                                             self.bn_rows[L.name], self.bn_sync, res_t, act))
             else:
                 _, _, scale, shift = pnn.bn_stats(z, gamma, beta, BN_EPS, self.bn_momentum,
                                                   self.bn_mean[L.name], self.bn_var[L.name],
                                                   self._workspace_for(M, L.cout),
                                                   out=self.bn_buf[L.name])
-            out = Var(pnn.bn_apply(z, scale, shift, res_t, act))
+                out = Var(pnn.bn_apply(z, scale, shift, res_t, act))
             if act and residual is None:
                 out.prod = (L, z, act)
             self.tape.append(("unit", L, x, residual, act, z, out))
@@ -346,12 +359,18 @@ class TrainGraph:
             z, rows = pnn.conv2d_bnstats(x.t, self.w(L), self._workspace_for(M, L.cout), L.stride,
                                          L.pad, **kw)
         if self.freeze_bn:
-            scale, shift = self.bn_rows[L.name][2], self.bn_rows[L.name][3]
+            r = self.bn_rows[L.name]
+            out = Var(pnn.bn_apply(z, r[2], r[3], res_t, act))
+        elif self.bn_sync is not None:
+            out = Var(pnn.bn_finalize_apply(self._ws, rows, z, gamma, beta, BN_EPS,
+                                            self.bn_momentum, self.bn_mean[L.name],
+                                            self.bn_var[L.name], self.bn_rows[L.name],
+                                            self.bn_sync, res_t, act))
         else:
             _, _, scale, shift = pnn.bn_finalize(
                 self._ws, rows, M, L.cout, gamma, beta, BN_EPS, self.bn_momentum,
                 self.bn_mean[L.name], self.bn_var[L.name], out=self.bn_rows[L.name])
-        out = Var(pnn.bn_apply(z, scale, shift, res_t, act))
+            out = Var(pnn.bn_apply(z, scale, shift, res_t, act))
         if act and residual is None:
             out.prod = (L, z, act)
         self.tape.append(("unit", L, x, residual, act, z, out))
@@ -462,7 +481,7 @@ class TrainGraph:
             x.dz = pnn.bn_bwd_from_partials(
                 g, zb, rows, self.view(self.master, Lb.name + ".bn.gamma"), buf[0], buf[1],
                 self._g(Lb.name + ".bn.gamma"), self._g(Lb.name + ".bn.beta"), ws,
-                frozen=self.freeze_bn)
+                frozen=self.freeze_bn, sync=self.bn_sync)
             x.grad = g
             return
         fused = x.grad is not None and not (L.k == 1 and L.stride == 2)
@@ -518,7 +537,8 @@ class TrainGraph:
                                    self._g(L.name + ".bn.gamma"), self._g(L.name + ".bn.beta"),
                                    self._workspace_for(z.numel() // L.cout, L.cout), masked,
                                    relu=act or 1, act_scale=buf[2] if rebuild else None,
-                                   act_shift=buf[3] if rebuild else None, frozen=self.freeze_bn)
+                                   act_shift=buf[3] if rebuild else None, frozen=self.freeze_bn,
+                                   sync=self.bn_sync)
                 if residual is not None:
                     self._acc(residual, g if masked else out.grad)
                 self._weight_grad(L, x.t, dz)

@@ -680,7 +680,8 @@ def deconv4x4s2_bwd_data_bnmask(dy: torch.Tensor, w_t: torch.Tensor, z: torch.Te
 
 
 def bn_bwd_from_partials(g: torch.Tensor, z: torch.Tensor, rows: int, gamma, mean, rstd, dgamma,
-                         dbeta, ws: torch.Tensor, dz=None, frozen: bool = False) -> torch.Tensor:
+                         dbeta, ws: torch.Tensor, dz=None, frozen: bool = False,
+                         sync=None) -> torch.Tensor:
     """Second half of the fused batch-norm backward: folds the `rows` partial rows a *_bnmask
     backward-data call left in `ws` and returns dz."""
     _check_act(g, "g")
@@ -693,7 +694,7 @@ def bn_bwd_from_partials(g: torch.Tensor, z: torch.Tensor, rows: int, gamma, mea
                                                  gamma.data_ptr(), mean.data_ptr(),
                                                  rstd.data_ptr(), dgamma.data_ptr(),
                                                  dbeta.data_ptr(), dz.data_ptr(), ws.data_ptr(),
-                                                 int(bool(frozen)), _stream(z)))
+                                                 int(bool(frozen)), _ptr(sync), _stream(z)))
     return dz
 
 
@@ -861,6 +862,61 @@ def bn_finalize(ws: torch.Tensor, rows: int, M: int, C: int, gamma, beta, eps: f
     return r[0], r[1], r[2], r[3]
 
 
+def bn_sync(device) -> torch.Tensor:
+    """The hand-off buffer of the one-launch batch-norm calls (an arrival counter that only
+    grows; the library tracks its value).  One per stream on which such calls are issued."""
+    dev = torch.device(device)
+    if dev.index is None:
+        dev = torch.device("cuda", torch.cuda.current_device())
+    n = lib().pe_bn_sync_bytes()
+    buf = torch.empty(n + 128, dtype=torch.uint8, device=dev)
+    off = (-buf.data_ptr()) % 128
+    sync = buf[off:off + n].view(torch.int32)
+    with torch.cuda.device(dev):
+        check(lib().pe_bn_sync_init(sync.data_ptr(),
+                                    torch.cuda.current_stream(dev).cuda_stream))
+    return sync
+
+
+def bn_finalize_apply(ws: torch.Tensor, rows: int, z: torch.Tensor, gamma, beta, eps: float,
+                      momentum: float, running_mean, running_var, out, sync: torch.Tensor,
+                      residual=None, relu: int = 1, y: Optional[torch.Tensor] = None):
+    """bn_finalize + bn_apply in one launch; `out` = the layer's (mean, rstd, scale, shift) rows.
+    Returns y."""
+    _check_act(z, "z")
+    C = z.shape[3]
+    M = z.numel() // C
+    r = out if isinstance(out, tuple) else out.unbind(0)
+    if y is None:
+        y = torch.empty_like(z)
+    with on_device(z):
+        check(lib().pe_bn_finalize_apply_bf16(
+            ws.data_ptr(), int(rows), z.data_ptr(), M, C, gamma.data_ptr(), beta.data_ptr(), eps,
+            momentum, _ptr(running_mean), _ptr(running_var), r[0].data_ptr(), r[1].data_ptr(),
+            r[2].data_ptr(), r[3].data_ptr(), _ptr(residual), int(relu), y.data_ptr(),
+            sync.data_ptr(), _stream(z)))
+    return y
+
+
+def bn_stats_apply(z: torch.Tensor, gamma, beta, eps: float, momentum: float, running_mean,
+                   running_var, ws: torch.Tensor, out, sync: torch.Tensor, residual=None,
+                   relu: int = 1, y: Optional[torch.Tensor] = None):
+    """bn_stats + bn_apply in two launches instead of three.  Returns y."""
+    _check_act(z, "z")
+    C = z.shape[3]
+    M = z.numel() // C
+    r = out if isinstance(out, tuple) else out.unbind(0)
+    if y is None:
+        y = torch.empty_like(z)
+    with on_device(z):
+        check(lib().pe_bn_stats_apply_bf16(
+            z.data_ptr(), M, C, gamma.data_ptr(), beta.data_ptr(), eps, momentum,
+            _ptr(running_mean), _ptr(running_var), r[0].data_ptr(), r[1].data_ptr(),
+            r[2].data_ptr(), r[3].data_ptr(), _ptr(residual), int(relu), y.data_ptr(),
+            ws.data_ptr(), sync.data_ptr(), _stream(z)))
+    return y
+
+
 def bn_apply(z: torch.Tensor, scale, shift, residual=None, relu: int = 1,
              out: Optional[torch.Tensor] = None) -> torch.Tensor:
     _check_act(z, "z")
@@ -876,7 +932,7 @@ def bn_apply(z: torch.Tensor, scale, shift, residual=None, relu: int = 1,
 
 def bn_bwd(da: torch.Tensor, a: Optional[torch.Tensor], z: torch.Tensor, gamma, mean, rstd,
            dgamma, dbeta, ws: torch.Tensor, want_masked: bool = False, dz=None, relu: int = 1,
-           act_scale=None, act_shift=None, frozen: bool = False):
+           act_scale=None, act_shift=None, frozen: bool = False, sync=None):
     """Returns (dz, g) where g = da masked by the activation that produced `a` (relu 1: ReLU,
     2: ReLU6; no mask when a is None); g is None unless want_masked.  For a layer without a
     residual, a = None with act_scale / act_shift (what its bn_apply used) rebuilds the mask from
@@ -893,5 +949,5 @@ def bn_bwd(da: torch.Tensor, a: Optional[torch.Tensor], z: torch.Tensor, gamma, 
                                    mean.data_ptr(), rstd.data_ptr(), _ptr(act_scale),
                                    _ptr(act_shift), dgamma.data_ptr(),
                                    dbeta.data_ptr(), dz.data_ptr(), _ptr(g), ws.data_ptr(),
-                                   int(bool(frozen)), _stream(z)))
+                                   int(bool(frozen)), _ptr(sync), _stream(z)))
     return dz, g

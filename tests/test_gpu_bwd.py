@@ -610,3 +610,61 @@ def test_fused_mask_argument_errors():
         pnn.conv2d_bwd_data_bnmask(dy, w_t, (8, 8), 1, 2, 0, z, sc, sc, ws)
     with pytest.raises(Exception):     # relu must say which activation
         pnn.conv2d_bwd_data_bnmask(torch.zeros_like(z), w_t, (8, 8), 1, 1, 0, z, sc, sc, ws, relu=0)
+
+
+@pytest.mark.parametrize("shape,relu", [((4, 16, 12, 64), 1), ((2, 8, 6, 2048), 1),
+                                        ((3, 10, 10, 96), 2), ((64, 64, 48, 64), 1),
+                                        ((2, 6, 5, 1000), 2), ((1, 4, 4, 8), 0)])
+def test_one_launch_batch_norm_equals_the_separate_launches(shape, relu):
+    """Finalize folded into the element-wise pass (an in-launch hand-off between workgroups)
+    against the separate finalize launch: every output bit for bit, forward and backward, with
+    and without a residual / stored activation, repeated back to back so that the hand-off words
+    are reused by consecutive launches; they must be zero afterwards and no wait may time out."""
+    B, H, W, C = shape
+    g = torch.Generator().manual_seed(59 + C)
+    M = B * H * W
+    z = (rnd(shape, g) * 2 + 0.5).to(BF16).cuda()
+    res = rnd(shape, g).to(BF16).cuda()
+    da = rnd(shape, g).to(BF16).cuda()
+    gamma = (torch.rand(C, generator=g) + 0.5).cuda()
+    beta = (torch.randn(C, generator=g) * 0.2).cuda()
+    rm0, rv0 = (torch.randn(C, generator=g) * 0.1).cuda(), (torch.rand(C, generator=g) + 0.5).cuda()
+    ws = pnn.bn_workspace(M, C, "cuda")
+    sync = pnn.bn_sync("cuda")
+
+    def separate(residual):
+        rm, rv = rm0.clone(), rv0.clone()
+        mean, rstd, scale, shift = pnn.bn_stats(z, gamma, beta, 1e-5, 0.1, rm, rv, ws)
+        a = pnn.bn_apply(z, scale, shift, residual, relu=relu)
+        dg, db = torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+        if residual is not None or relu == 0:
+            dz, gm = pnn.bn_bwd(da, a if relu else None, z, gamma, mean, rstd, dg, db, ws,
+                                want_masked=True, relu=relu or 1)
+        else:
+            dz, gm = pnn.bn_bwd(da, None, z, gamma, mean, rstd, dg, db, ws, want_masked=True,
+                                relu=relu, act_scale=scale, act_shift=shift)
+        return [t.clone() for t in (mean, rstd, scale, shift, rm, rv, a, dz, gm, dg, db)]
+
+    def fused(residual):
+        rm, rv = rm0.clone(), rv0.clone()
+        rows = torch.empty(4, C, device="cuda")
+        a = pnn.bn_stats_apply(z, gamma, beta, 1e-5, 0.1, rm, rv, ws, rows, sync, residual, relu)
+        mean, rstd, scale, shift = rows.unbind(0)
+        dg, db = torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+        if residual is not None or relu == 0:
+            dz, gm = pnn.bn_bwd(da, a if relu else None, z, gamma, mean, rstd, dg, db, ws,
+                                want_masked=True, relu=relu or 1, sync=sync)
+        else:
+            dz, gm = pnn.bn_bwd(da, None, z, gamma, mean, rstd, dg, db, ws, want_masked=True,
+                                relu=relu, act_scale=scale, act_shift=shift, sync=sync)
+        return [t.clone() for t in (mean, rstd, scale, shift, rm, rv, a, dz, gm, dg, db)]
+
+    names = "mean rstd scale shift running_mean running_var a dz masked dgamma dbeta".split()
+    for residual in (None, res):
+        want = separate(residual)
+        for rep in range(6):
+            got = fused(residual)
+            for nm, x, y in zip(names, got, want):
+                assert torch.equal(x, y), (nm, rep)
+    torch.cuda.synchronize()
+    assert int(sync[512]) == 0, "a wait for the fold workgroups timed out"
