@@ -32,6 +32,12 @@ __device__ __forceinline__ float aug_tap(const uint8_t* __restrict__ img, int Hs
     return ok ? v : 0.0f;
 }
 
+// 8 bytes from any byte address (gfx950 global loads need no alignment).
+__device__ __forceinline__ uint64_t load_u64_unaligned(const uint8_t* p) {
+    struct __attribute__((packed, aligned(1))) U64 { uint64_t v; };
+    return reinterpret_cast<const U64*>(p)->v;
+}
+
 __global__ __launch_bounds__(256) void augment_s2d_kernel(const uint8_t* __restrict__ img, int B,
                                                           int Hs, int Ws,
                                                           const float* __restrict__ params, int H2,
@@ -65,14 +71,36 @@ __global__ __launch_bounds__(256) void augment_s2d_kernel(const uint8_t* __restr
             const float uf = floorf(u);
             const float fx = u - uf;
             const int x0 = (int)fminf(fmaxf(uf, -1.0e9f), 1.0e9f);
+            // Interior pixels (all four taps in the frame, and the 8 bytes from the left tap on
+            // still inside the row): the two taps of a row are 6 consecutive bytes, fetched by
+            // one unaligned 8-byte load instead of six byte loads.  Same values, same arithmetic.
+            const bool inner = x0 >= 0 && x0 + 3 <= Ws && y0 >= 0 && y0 + 1 < Hs &&
+                               (long)x0 * 3 + 8 <= (long)Ws * 3;
+            float p00[3], p01[3], p10[3], p11[3];
+            if (inner) {
+                const uint8_t* r0 = src + ((long)y0 * Ws + x0) * 3;
+                const uint64_t a0 = load_u64_unaligned(r0);
+                const uint64_t a1 = load_u64_unaligned(r0 + (long)Ws * 3);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    p00[c] = (float)(uint32_t)((a0 >> (8 * c)) & 0xffu);
+                    p01[c] = (float)(uint32_t)((a0 >> (8 * (c + 3))) & 0xffu);
+                    p10[c] = (float)(uint32_t)((a1 >> (8 * c)) & 0xffu);
+                    p11[c] = (float)(uint32_t)((a1 >> (8 * (c + 3))) & 0xffu);
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    p00[c] = aug_tap(src, Hs, Ws, y0, x0, c);
+                    p01[c] = aug_tap(src, Hs, Ws, y0, x0 + 1, c);
+                    p10[c] = aug_tap(src, Hs, Ws, y0 + 1, x0, c);
+                    p11[c] = aug_tap(src, Hs, Ws, y0 + 1, x0 + 1, c);
+                }
+            }
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-                const float p00 = aug_tap(src, Hs, Ws, y0, x0, c);
-                const float p01 = aug_tap(src, Hs, Ws, y0, x0 + 1, c);
-                const float p10 = aug_tap(src, Hs, Ws, y0 + 1, x0, c);
-                const float p11 = aug_tap(src, Hs, Ws, y0 + 1, x0 + 1, c);
-                const float top = p00 + fx * (p01 - p00);
-                const float bot = p10 + fx * (p11 - p10);
+                const float top = p00[c] + fx * (p01[c] - p00[c]);
+                const float bot = p10[c] + fx * (p11[c] - p10[c]);
                 const float val = top + fy * (bot - top);
                 h[(ry * 2 + rx) * 3 + c] = (val / 255.0f - nm.mean[c]) * nm.inv_std[c];
             }

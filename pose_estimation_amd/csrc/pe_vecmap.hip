@@ -115,19 +115,31 @@ __global__ __launch_bounds__(256) void vec_loss_kernel(VecLossArgs a) {
                                                      map * (long)n * (BF16 ? 2 : 4))
                           : nullptr;
     const uint8_t* mrow = HAS_MASK ? a.mask + b * (long)n : nullptr;
+    // Pass 1: the gradient is zero almost everywhere.  These stores depend on nothing, so they
+    // stream out while the joints that place the window are still being loaded.
+    if (HAS_GRAD) {
+        const u32x4 zero = {0u, 0u, 0u, 0u};
+#pragma unroll 4
+        for (int q = lane; q < nch; q += 64) __builtin_nontemporal_store(zero, g16 + q);
+    }
+    // Pass 2: the chunks that touch the window, one per lane (a window of radius 2 has about 15),
+    // so their pred loads are all in flight together.  A window chunk is written by another lane
+    // than the one that zeroed it: the zero stores are waited for first, which orders the two
+    // writes of that address.  Lane sums are folded in a fixed order (bit-stable loss).
     float acc = 0.0f;
-#pragma unroll 2
-    for (int q = lane; q < nch; q += 64) {
-        const int y = q / wch;
-        const int x0 = (q - y * wch) * CH;
-        // rows and chunks that miss the window leave a zero gradient without touching pred
-        const bool near = w.on && abs(y - w.sy) <= a.radius && x0 + (CH - 1) >= w.sx - a.radius &&
-                          x0 <= w.sx + a.radius;
-        float gr[CH];
-#pragma unroll
-        for (int i = 0; i < CH; ++i) gr[i] = 0.0f;
-        if (near) {
-            float p[CH];
+    if (w.on) {
+        const int ylo = max(w.sy - a.radius, 0), yhi = min(w.sy + a.radius, a.H - 1);
+        const int xlo = max(w.sx - a.radius, 0), xhi = min(w.sx + a.radius, a.W - 1);
+        const int clo = xlo / CH, chi = xhi / CH;
+        const int ncx = chi - clo + 1;
+        const int nwin = (yhi >= ylo && xhi >= xlo) ? (yhi - ylo + 1) * ncx : 0;
+        if (HAS_GRAD && nwin > 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        for (int j = lane; j < nwin; j += 64) {
+            const int y = ylo + j / ncx;
+            const int cx = clo + j % ncx;
+            const int q = y * wch + cx;
+            const int x0 = cx * CH;
+            float p[CH], gr[CH];
             const u32x4 pv = __builtin_nontemporal_load(p16 + q);
             if constexpr (BF16) {
                 const uint32_t u[4] = {pv.x, pv.y, pv.z, pv.w};
@@ -152,21 +164,21 @@ __global__ __launch_bounds__(256) void vec_loss_kernel(VecLossArgs a) {
                 acc += in ? sq : 0.0f;
                 gr[i] = in ? a.inv_n * d : 0.0f;
             }
-        }
-        if (HAS_GRAD) {
-            u32x4 o;
-            if constexpr (BF16) {
-                o.x = pack_bf16x2_bits(gr[0], gr[1]);
-                o.y = pack_bf16x2_bits(gr[2], gr[3]);
-                o.z = pack_bf16x2_bits(gr[4], gr[5]);
-                o.w = pack_bf16x2_bits(gr[6], gr[7]);
-            } else {
-                o.x = __float_as_uint(gr[0]);
-                o.y = __float_as_uint(gr[1]);
-                o.z = __float_as_uint(gr[2]);
-                o.w = __float_as_uint(gr[3]);
+            if (HAS_GRAD) {
+                u32x4 o;
+                if constexpr (BF16) {
+                    o.x = pack_bf16x2_bits(gr[0], gr[1]);
+                    o.y = pack_bf16x2_bits(gr[2], gr[3]);
+                    o.z = pack_bf16x2_bits(gr[4], gr[5]);
+                    o.w = pack_bf16x2_bits(gr[6], gr[7]);
+                } else {
+                    o.x = __float_as_uint(gr[0]);
+                    o.y = __float_as_uint(gr[1]);
+                    o.z = __float_as_uint(gr[2]);
+                    o.w = __float_as_uint(gr[3]);
+                }
+                __builtin_nontemporal_store(o, g16 + q);
             }
-            __builtin_nontemporal_store(o, g16 + q);
         }
     }
     acc = wave_sum(acc);
