@@ -31,6 +31,7 @@ struct WgradParams {
     int Cin, cshift, cmask, T;
     int OH, OW, osy, osx, ooy, oox, ldy;
     long m_per_split;    // filled in by wgrad_launch
+    int tiles, splits;   // filled in by wgrad_launch: 128 x 128 output tiles, pixel splits
     int16_t tap_dy[kMaxTaps];
     int16_t tap_dx[kMaxTaps];
 };

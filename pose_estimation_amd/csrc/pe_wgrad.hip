@@ -22,6 +22,8 @@
 // the slabs to dW in a fixed order: no float atomics, so a step repeats bit for bit.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "pe_common.h"
 #include "pe_wgrad.h"
 
@@ -59,11 +61,22 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* tile, int off_lo) {
 
 // FLAT: a 1x1 stride-1 conv with an identity output grid, where input pixel = output pixel =
 // GEMM row and the per-step index split disappears (two thirds of the network's layers).
-template <bool FLAT>
-__global__ __launch_bounds__(256, 4) void wgrad_kernel(const WgradParams p) {
+template <int N>
+__device__ __forceinline__ void wg_wait_vmcnt() {
+    static_assert(N >= 0 && N <= 63, "vmcnt immediate out of range");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// NS = 1: one LDS stage, load - barrier - multiply - barrier; four workgroups per CU cover each
+// other's load latency.  NS >= 2: a ring of NS stages with the loads of the next NS-1 K steps in
+// flight (counted vmcnt, one raw barrier per step), for launches that put only one or two
+// workgroups on a CU: every pixel split costs a slab of the weight's size, so large weights run
+// with few splits and must hide their own latency.
+template <bool FLAT, int NS>
+__global__ __launch_bounds__(256, NS == 1 ? 4 : (NS == 2 ? 2 : 1)) void wgrad_kernel(
+    const WgradParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* ytile = smem;
-    char* xtile = smem + WG_TILE;
+    constexpr int STAGE = 2 * WG_TILE;   // dy tile, then x tile
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -73,13 +86,25 @@ __global__ __launch_bounds__(256, 4) void wgrad_kernel(const WgradParams p) {
 
     const int ktot = p.T * p.Cin;
     const int ntn = (p.N + 127) / 128;
-    const int tile_c = blockIdx.x / ntn;
-    const int tile_n = blockIdx.x - tile_c * ntn;
+    // XCD-aware order: workgroups that share an XCD (ids congruent mod 8) take a contiguous run
+    // of (split, tile) pairs, so the tiles of one pixel split, which all read the same dy and x
+    // rows, find them in ONE L2 instead of pulling a copy into each of the eight
+    int bid = blockIdx.x;
+    {
+        const int nwg = gridDim.x;
+        const int qq = nwg >> 3, r8 = nwg & 7;
+        const int xcd = bid & 7, loc = bid >> 3;
+        bid = (xcd < r8 ? xcd * (qq + 1) : r8 * (qq + 1) + (xcd - r8) * qq) + loc;
+    }
+    const int split = bid / p.tiles;
+    const int tile = bid - split * p.tiles;
+    const int tile_c = tile / ntn;
+    const int tile_n = tile - tile_c * ntn;
     const int n0 = tile_n * 128;
     const int c0 = tile_c * 128;
 
     const long M = (long)p.B * p.Ho * p.Wo;
-    const long ms = (long)blockIdx.y * p.m_per_split;
+    const long ms = (long)split * p.m_per_split;
     long me = ms + p.m_per_split;
     if (me > M) me = M;
 
@@ -127,7 +152,10 @@ __global__ __launch_bounds__(256, 4) void wgrad_kernel(const WgradParams p) {
         xoff[t] = frow * WG_ROWB + (((2 * (wave_c * 4 + t) + fsub) ^ fsw) * 16) + fbyte;
     }
 
-    for (long mb = ms; mb < me; mb += WG_BK) {
+    // issues the loads of the K step that starts at pixel mb into `stage`
+    auto issue = [&](char* stage, long mb) {
+        char* ytile = stage;
+        char* xtile = stage + WG_TILE;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const long m = mb + rr + 16 * i;
@@ -155,7 +183,10 @@ __global__ __launch_bounds__(256, 4) void wgrad_kernel(const WgradParams p) {
             __builtin_amdgcn_global_load_lds((gptr_t)xsrc,
                                              (lptr_t)(xtile + (16 * i + 4 * wid) * WG_ROWB), 16, 0, 0);
         }
-        __syncthreads();  // vmcnt drained by the compiler: tiles are in LDS
+    };
+    auto multiply = [&](const char* stage) {
+        const char* ytile = stage;
+        const char* xtile = stage + WG_TILE;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             bf16x8 fx[4], fy[4];
@@ -169,7 +200,80 @@ __global__ __launch_bounds__(256, 4) void wgrad_kernel(const WgradParams p) {
                 for (int b = 0; b < 4; ++b)
                     acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fx[a], fy[b], acc[a][b], 0, 0, 0);
         }
-        __syncthreads();  // tiles consumed before the next K step overwrites them
+    };
+
+    // The ring's fragment reads are written in assembly: for the transposing-read intrinsic the
+    // compiler waits for EVERY outstanding load (vmcnt(0)) before the first read of a K step,
+    // which would drain the prefetched stages and serialise the ring.  An asm read is invisible
+    // to that pass; its result is awaited by the explicit lgkmcnt wait below, and the scheduling
+    // barrier keeps the multiplies behind that wait.
+    auto tr_read = [](uint32_t addr, auto off) -> uint64_t {
+        uint64_t v;
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=&v"(v) : "v"(addr), "n"(decltype(off)::value));
+        return v;
+    };
+    auto frag_of = [](uint64_t lo, uint64_t hi) -> bf16x8 {
+        typedef uint64_t u64x2 __attribute__((ext_vector_type(2)));
+        const u64x2 v = {lo, hi};
+        return __builtin_bit_cast(bf16x8, v);
+    };
+    auto multiply_ring = [&](uint32_t stage_addr) {
+        // stage_addr: LDS byte address of the stage; dy tile first, x tile at +WG_TILE
+#define PE_TR(BASE, OFF) tr_read((BASE), std::integral_constant<int, (OFF)>{})
+#define PE_KS(KS)                                                                              \
+        {                                                                                      \
+            uint64_t xl[4], xh[4], yl[4], yh[4];                                               \
+            _Pragma("unroll") for (int a = 0; a < 4; ++a) {                                    \
+                xl[a] = PE_TR(stage_addr + xoff[a], WG_TILE + (KS) * 32 * WG_ROWB);            \
+                xh[a] = PE_TR(stage_addr + xoff[a], WG_TILE + (KS) * 32 * WG_ROWB + 16 * WG_ROWB); \
+            }                                                                                  \
+            _Pragma("unroll") for (int b = 0; b < 4; ++b) {                                    \
+                yl[b] = PE_TR(stage_addr + yoff[b], (KS) * 32 * WG_ROWB);                      \
+                yh[b] = PE_TR(stage_addr + yoff[b], (KS) * 32 * WG_ROWB + 16 * WG_ROWB);       \
+            }                                                                                  \
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                 \
+            __builtin_amdgcn_sched_barrier(0);                                                 \
+            _Pragma("unroll") for (int a = 0; a < 4; ++a)                                      \
+                _Pragma("unroll") for (int b = 0; b < 4; ++b)                                  \
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                       \
+                        frag_of(xl[a], xh[a]), frag_of(yl[b], yh[b]), acc[a][b], 0, 0, 0);     \
+        }
+        PE_KS(0)
+        PE_KS(1)
+#undef PE_KS
+#undef PE_TR
+    };
+
+    if constexpr (NS >= 2) {
+        // see the ring in pe_igemm.hip: a stage is read only after the counted wait that retires
+        // its loads AND a barrier, and restaged only after a barrier that follows its last read
+        constexpr int LPT = 8;   // staging instructions per thread and K step
+        static_assert((NS - 2) * LPT <= 63, "too many loads in flight for the vmcnt field");
+        const int KT = (int)((me - ms + WG_BK - 1) / WG_BK);
+        const uint32_t smem_addr = (uint32_t)(uintptr_t)(lptr_t)smem;
+#pragma unroll
+        for (int st = 0; st < NS - 1; ++st)
+            if (st < KT) issue(smem + st * STAGE, ms + (long)st * WG_BK);
+        int cur = 0, nxt = NS - 1;
+        for (int kt = 0; kt < KT; ++kt) {
+            if (kt + NS - 1 <= KT) wg_wait_vmcnt<(NS - 2) * LPT>();
+            else wg_wait_vmcnt<0>();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (kt + NS - 1 < KT) issue(smem + nxt * STAGE, ms + (long)(kt + NS - 1) * WG_BK);
+            multiply_ring(smem_addr + (uint32_t)(cur * STAGE));
+            if (++cur == NS) cur = 0;
+            if (++nxt == NS) nxt = 0;
+        }
+        __syncthreads();   // the epilogue reuses the stages
+    } else {
+        for (long mb = ms; mb < me; mb += WG_BK) {
+            issue(smem, mb);
+            __syncthreads();  // vmcnt drained by the compiler: tiles are in LDS
+            multiply(smem);
+            __syncthreads();  // tiles consumed before the next K step overwrites them
+        }
     }
 
     // ---- epilogue: n halves through LDS [64 n][128 cols] (pitch 132 floats), then stores in
@@ -194,13 +298,13 @@ __global__ __launch_bounds__(256, 4) void wgrad_kernel(const WgradParams p) {
         if (colg < ktot) {
             // one split: this workgroup owns the elements, add in place; several splits: each
             // writes its own slab with plain stores and wgrad_reduce_kernel folds them in order
-            float* dst = gridDim.y == 1 ? p.dw : p.slab + (long)blockIdx.y * p.slab_stride;
+            float* dst = p.splits == 1 ? p.dw : p.slab + (long)split * p.slab_stride;
             for (int nl = tid >> 7; nl < 64; nl += 2) {
                 const int n = n0 + half * 64 + nl;
                 if (n >= p.Nw) break;
                 const long e = (long)n * ktot + colg;
                 const float v = cs[nl * CP + cl];
-                dst[e] = gridDim.y == 1 ? dst[e] + v : v;
+                dst[e] = p.splits == 1 ? dst[e] + v : v;
             }
         }
         __syncthreads();
@@ -273,7 +377,14 @@ int32_t wgrad_launch(WgradParams& p, void* workspace, size_t workspace_bytes, hi
     const long big_tiles = tune_t ? atol(tune_t) : kWgradBigTiles;
     // a weight with many output tiles fills the chip with fewer pixel splits, and every split
     // costs a slab of the weight's size to write and fold
-    long target = tune ? atol(tune) : (tiles >= big_tiles ? kWgradTargetBlocks / 2 : kWgradTargetBlocks);
+    const bool flat = p.T == 1 && p.tap_dy[0] == 0 && p.tap_dx[0] == 0 && p.sy == 1 && p.sx == 1 &&
+                      p.Hi == p.Ho && p.Wi == p.Wo && p.OH == p.Ho && p.OW == p.Wo && p.osy == 1 &&
+                      p.osx == 1 && p.ooy == 0 && p.oox == 0 && p.cshift == 31;
+    // 1x1 layers run the two-stage ring with one workgroup per CU (fewer slabs to write and
+    // fold: 237 against 218 TFLOP/s over the ResNet-50 1x1 shapes at batch 64); the others keep
+    // the single stage, whose per-step index arithmetic needs several workgroups per CU to hide
+    long target = tune ? atol(tune)
+                       : ((tiles >= big_tiles || flat) ? kWgradTargetBlocks / 2 : kWgradTargetBlocks);
     if (target < 1 || target > kWgradMaxBlocks) target = kWgradTargetBlocks;
     long splits = (target + tiles - 1) / tiles;
     const long max_splits = (M + 255) / 256;
@@ -292,14 +403,34 @@ int32_t wgrad_launch(WgradParams& p, void* workspace, size_t workspace_bytes, hi
                    "%s: workspace too small (%zu bytes needed)", what,
                    (size_t)splits * (size_t)P * sizeof(float));
     }
-    const size_t lds = 64 * 132 * sizeof(float);  // epilogue half tile (33.8 KB) > K tiles (32 KB)
-    const bool flat = p.T == 1 && p.tap_dy[0] == 0 && p.tap_dx[0] == 0 && p.sy == 1 && p.sx == 1 &&
-                      p.Hi == p.Ho && p.Wi == p.Wo && p.OH == p.Ho && p.OW == p.Wo && p.osy == 1 &&
-                      p.osx == 1 && p.ooy == 0 && p.oox == 0 && p.cshift == 31;
-    if (flat)
-        wgrad_kernel<true><<<dim3((unsigned)tiles, (unsigned)splits), 256, lds, st>>>(p);
-    else
-        wgrad_kernel<false><<<dim3((unsigned)tiles, (unsigned)splits), 256, lds, st>>>(p);
+    const size_t lds1 = 64 * 132 * sizeof(float);  // epilogue half tile (33.8 KB) > K tiles (32 KB)
+    // PE_WGRAD_NS forces the stage count (1, 2, 3 or 4)
+    static const char* tune_ns = getenv("PE_WGRAD_NS");
+    const long nwg = tiles * splits;
+    int ns = (flat && nwg <= 640) ? 2 : 1;
+    if (tune_ns) ns = atoi(tune_ns);
+    p.tiles = (int)tiles;
+    p.splits = (int)splits;
+    const dim3 grid((unsigned)(tiles * splits));
+#define PE_WG(FLAT_, NS_)                                                                 \
+    {                                                                                     \
+        constexpr size_t lds = NS_ == 1 ? lds1 : (size_t)NS_ * 2 * WG_TILE;              \
+        if constexpr (lds > 64 * 1024) {                                                  \
+            static const hipError_t once = hipFuncSetAttribute(                           \
+                reinterpret_cast<const void*>(&wgrad_kernel<FLAT_, NS_>),                 \
+                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                    \
+            (void)once;                                                                   \
+        }                                                                                 \
+        wgrad_kernel<FLAT_, NS_><<<grid, 256, lds, st>>>(p);                              \
+    }
+    if (flat) {
+        if (ns == 4) PE_WG(true, 4) else if (ns == 3) PE_WG(true, 3)
+        else if (ns == 2) PE_WG(true, 2) else PE_WG(true, 1)
+    } else {
+        if (ns == 4) PE_WG(false, 4) else if (ns == 3) PE_WG(false, 3)
+        else if (ns == 2) PE_WG(false, 2) else PE_WG(false, 1)
+    }
+#undef PE_WG
     int32_t rc = check_launch(what);
     if (rc != PE_OK || splits == 1) return rc;
     const long groups = P >> 2;
