@@ -317,6 +317,17 @@ int32_t pe_transform_joints_f32(const float* joints_in, int32_t B, int32_t K,
                                 const int32_t* flip_perm_host, float* joints_out,
                                 pe_stream_t stream);
 
+/* The per-pixel ignore mask (`labels['masks']`, test.ipynb:949) under the same map: mask_in
+ * [B,Hms,Wms] uint8 covers the SOURCE frame in cells of src_stride pixels, mask_out [B,Hm,Wm]
+ * covers the output image in cells of `stride` pixels.  The centre of output cell (x, y),
+ *   xc = (x + 0.5)*stride - 0.5 (mirrored to (Wm*stride - 1) - xc when flipped), yc likewise,
+ * goes through the image map (u, v) and reads source cell (floor((u + 0.5)/src_stride),
+ * floor((v + 0.5)/src_stride)); a centre outside the source frame gives `fill` (0..255).
+ * float32 arithmetic in this order; mask_out must not alias mask_in. */
+int32_t pe_augment_mask_u8(const uint8_t* mask_in, int32_t B, int32_t Hms, int32_t Wms,
+                           float src_stride, const float* params_device, int32_t Hm, int32_t Wm,
+                           float stride, int32_t fill, uint8_t* mask_out, pe_stream_t stream);
+
 /* 3x3 stride-2 pad-1 max pool, NHWC bf16: [B,H,W,C] -> [B,H/2,W/2,C] (H, W even; C % 8 == 0).
  * idx (may be NULL; training passes it): uint8 [B,H/2,W/2,C], the window position ky*3+kx of
  * each output's first maximum in row-major scan order. */

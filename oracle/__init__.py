@@ -23,6 +23,7 @@ from .numpy_oracle import (  # noqa: F401
     render_targets,
     render_vecmaps,
     augment_u8,
+    augment_mask,
     transform_joints,
     vecmap_loss_fwd_bwd,
     ssd_anchors,

@@ -198,6 +198,40 @@ def augment_u8(img_u8, params, out_hw, mean, std):
     return bf16_round(out)
 
 
+def augment_mask(mask, params, src_stride: float, out_hw, stride: float, fill: int = 1):
+    """Ignore mask [B,Hms,Wms] over the source frame (cells of src_stride pixels) -> uint8
+    [B,Hm,Wm] over the output image (cells of `stride` pixels) under augment_u8's map, nearest
+    sampling at the cell centre: xc = (x+.5)*stride - .5 (mirrored to (Wm*stride - 1) - xc when
+    flipped), u = (xc+.5)*sx + tx - .5, source cell floor((u+.5)/src_stride); outside -> fill.
+    float32, one operation at a time.  The reference's `masks` label (test.ipynb:949) went through
+    the same tf.data map as the image; its code (dataset/pose_data.py) is absent."""
+    m = np.asarray(mask).astype(np.uint8)
+    prm = np.asarray(params, dtype=F32)
+    B, Hms, Wms = m.shape
+    Hm, Wm = out_hw
+    st, ss = F32(stride), F32(src_stride)
+    out = np.empty((B, Hm, Wm), np.uint8)
+    xs = np.arange(Wm, dtype=F32)
+    ys = np.arange(Hm, dtype=F32)
+    Wpx = (F32(Wm) * st).astype(F32)
+    for b in range(B):
+        sx, sy, tx, ty, flip = (F32(v) for v in prm[b])
+        xc = ((xs + F32(0.5)) * st).astype(F32) - F32(0.5)
+        yc = ((ys + F32(0.5)) * st).astype(F32) - F32(0.5)
+        xf = ((Wpx - F32(1.0)).astype(F32) - xc).astype(F32) if flip != 0 else xc
+        u = (((xf + F32(0.5)) * sx).astype(F32) + tx).astype(F32) - F32(0.5)
+        v = (((yc + F32(0.5)) * sy).astype(F32) + ty).astype(F32) - F32(0.5)
+        cu = np.floor(((u + F32(0.5)).astype(F32) / ss).astype(F32))
+        cv = np.floor(((v + F32(0.5)).astype(F32) / ss).astype(F32))
+        okx = (cu >= 0) & (cu < Wms)
+        oky = (cv >= 0) & (cv < Hms)
+        ix = np.clip(cu, 0, Wms - 1).astype(np.int64)
+        iy = np.clip(cv, 0, Hms - 1).astype(np.int64)
+        g = m[b][iy[:, None], ix[None, :]]
+        out[b] = np.where(oky[:, None] & okx[None, :], g, np.uint8(fill))
+    return out
+
+
 def transform_joints(joints, params, out_w: int, flip_perm=None):
     """Inverse of augment_u8's map for joints [B,K,3]: xo = (x + .5 - tx)/sx - .5 (W-1-xo when
     flipped), yo likewise; when flipped, output joint k is source joint flip_perm[k]."""

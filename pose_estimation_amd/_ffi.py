@@ -112,6 +112,9 @@ SIGNATURES = {
         [c_void_p, c_int32, c_int32, c_int32, c_void_p, c_int32, c_int32, c_void_p, c_void_p,
          c_void_p, c_void_p],
     ),
+    "pe_augment_mask_u8": (
+        c_int32, [c_void_p, c_int32, c_int32, c_int32, c_float, c_void_p, c_int32, c_int32,
+                  c_float, c_int32, c_void_p, c_void_p]),
     "pe_transform_joints_f32": (
         c_int32, [c_void_p, c_int32, c_int32, c_void_p, c_int32, c_void_p, c_void_p, c_void_p],
     ),

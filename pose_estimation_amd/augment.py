@@ -96,3 +96,26 @@ def transform_joints(joints: torch.Tensor, params: torch.Tensor, out_w: int,
                                             ctypes.addressof(perm) if perm is not None else None,
                                             out.data_ptr(), _stream(joints)))
     return out
+
+
+def augment_mask(mask: torch.Tensor, params: torch.Tensor, src_stride: float,
+                 out_hw: Tuple[int, int], stride: float, fill: int = 1) -> torch.Tensor:
+    """Ignore mask uint8/bool [B,Hms,Wms] over the source frame (cells of src_stride pixels) ->
+    uint8 [B,Hm,Wm] over the output image (cells of `stride` pixels) under the map of `params`;
+    cells whose centre leaves the source frame get `fill` (1 = trained as background)."""
+    _need_gpu(mask, params)
+    if mask.dtype == torch.bool:
+        mask = mask.view(torch.uint8)
+    if mask.dtype != torch.uint8 or mask.dim() != 3:
+        raise ValueError("mask must be uint8 or bool [B,Hms,Wms]")
+    mask = mask.contiguous()
+    B, Hms, Wms = mask.shape
+    if params.dtype != torch.float32 or tuple(params.shape) != (B, 5) or not params.is_contiguous():
+        raise ValueError("params must be contiguous float32 [B,5]")
+    Hm, Wm = out_hw
+    out = torch.empty((B, Hm, Wm), dtype=torch.uint8, device=mask.device)
+    with on_device(mask):
+        check(lib().pe_augment_mask_u8(mask.data_ptr(), B, Hms, Wms, float(src_stride),
+                                       params.data_ptr(), int(Hm), int(Wm), float(stride),
+                                       int(fill), out.data_ptr(), _stream(mask)))
+    return out

@@ -146,9 +146,62 @@ __global__ __launch_bounds__(256) void transform_joints_kernel(const float* __re
     d[2] = s[2];
 }
 
+// The ignore mask follows the image map: output mask cell (x, y) of size `stride` pixels takes
+// the value of the source mask cell (size src_stride pixels of the source frame) that its centre
+// maps to, nearest sampling; centres that leave the source frame take `fill`.
+__global__ __launch_bounds__(256) void augment_mask_kernel(const uint8_t* __restrict__ min, int B,
+                                                           int Hms, int Wms, float src_stride,
+                                                           const float* __restrict__ params,
+                                                           int Hm, int Wm, float stride, int fill,
+                                                           uint8_t* __restrict__ mout) {
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    const long total = (long)B * Hm * Wm;
+    if (t >= total) return;
+    const int x = (int)(t % Wm);
+    const long r = t / Wm;
+    const int y = (int)(r % Hm);
+    const long b = r / Hm;
+    const float sx = params[b * 5 + 0], sy = params[b * 5 + 1];
+    const float tx = params[b * 5 + 2], ty = params[b * 5 + 3];
+    const bool flip = params[b * 5 + 4] != 0.0f;
+    const float W = (float)Wm * stride;
+    // centre of the cell in output pixel index coordinates, then the image map
+    const float xc = ((float)x + 0.5f) * stride - 0.5f;
+    const float yc = ((float)y + 0.5f) * stride - 0.5f;
+    const float xf = flip ? (W - 1.0f) - xc : xc;
+    const float u = (xf + 0.5f) * sx + tx - 0.5f;
+    const float v = (yc + 0.5f) * sy + ty - 0.5f;
+    const float cu = floorf((u + 0.5f) / src_stride);
+    const float cv = floorf((v + 0.5f) / src_stride);
+    int val = fill;
+    if (cu >= 0.0f && cu < (float)Wms && cv >= 0.0f && cv < (float)Hms)
+        val = min[(b * Hms + (long)cv) * Wms + (long)cu];
+    mout[t] = (uint8_t)val;
+}
+
 }  // namespace pe
 
 using namespace pe;
+
+extern "C" int32_t pe_augment_mask_u8(const uint8_t* mask_in, int32_t B, int32_t Hms, int32_t Wms,
+                                      float src_stride, const float* params_device, int32_t Hm,
+                                      int32_t Wm, float stride, int32_t fill, uint8_t* mask_out,
+                                      pe_stream_t stream) {
+    const char* what = "pe_augment_mask_u8";
+    PE_REQUIRE(mask_in && params_device && mask_out, PE_E_INVALID, "%s: NULL pointer", what);
+    PE_REQUIRE(B > 0 && Hms > 0 && Wms > 0 && Hm > 0 && Wm > 0, PE_E_INVALID,
+               "%s: sizes must be positive", what);
+    PE_REQUIRE(src_stride > 0.0f && stride > 0.0f && isfinite(src_stride) && isfinite(stride),
+               PE_E_INVALID, "%s: strides must be positive and finite", what);
+    PE_REQUIRE(fill >= 0 && fill <= 255, PE_E_INVALID, "%s: fill must be a byte", what);
+    PE_REQUIRE(mask_in != mask_out, PE_E_INVALID, "%s: in-place warp is not supported", what);
+    const long total = (long)B * Hm * Wm;
+    PE_REQUIRE(total < 0x7fffffffL && (long)B * Hms * Wms < 0x7fffffffL, PE_E_UNSUPPORTED,
+               "%s: too many cells", what);
+    augment_mask_kernel<<<(unsigned)((total + 255) / 256), 256, 0, as_stream(stream)>>>(
+        mask_in, B, Hms, Wms, src_stride, params_device, Hm, Wm, stride, fill, mask_out);
+    return check_launch(what);
+}
 
 extern "C" int32_t pe_augment_u8_s2d_bf16(const uint8_t* img, int32_t B, int32_t Hs, int32_t Ws,
                                           const float* params_device, int32_t H, int32_t W,

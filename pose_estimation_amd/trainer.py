@@ -125,7 +125,6 @@ class Trainer:
         sigma = float(self.model_cfg.sigma)
         i = 0
         rank = self._rank()      # every data-parallel rank draws its own shard of the batch
-        aug = bool(getattr(self.train_cfg, "augmentation", None))
         while num_batches is None or i < num_batches:
             seed = int(self.data_cfg.seed) + 1000 * i + 100003 * rank
             img = torch.from_numpy(synthetic.images_u8(B, H, W, seed + 1)).to(self.device)
@@ -134,11 +133,9 @@ class Trainer:
             radius = self.model_cfg.get("radius")
             hm, w = ops.render_targets(joints, H // s, W // s, float(s), sigma,
                                        None if radius is None else int(radius), layout="NHWC")
-            labels = {"heatmaps": hm, "joints": joints, "weights": w}
-            if not aug:
-                # an ignore mask is tied to the frame it was drawn on: with augmentation
-                # configured, train_step re-maps frames and joints and takes no mask
-                labels["masks"] = mask
+            # the mask covers the frame it was drawn on; train_step warps it with the frame when
+            # it resizes or augments
+            labels = {"heatmaps": hm, "joints": joints, "weights": w, "masks": mask}
             pairs = self.model_cfg.get("pairs")
             if pairs:   # the reference's second dense label (test.ipynb:925-944)
                 labels["vecmaps"] = ops.render_vecmaps(joints, [tuple(p) for p in pairs], H // s,
@@ -165,10 +162,7 @@ class Trainer:
         aug_cfg = getattr(t, "augmentation", None)
         if aug_cfg or tuple(images.shape[1:3]) != (H, W):
             # frames of any size: resize (+ the configured augmentation) on the GPU, straight
-            # into the stem's input layout; joints follow the same map
-            if mask is not None:
-                raise ValueError("an ignore mask cannot follow the resize/augmentation map; "
-                                 "pass frames at image_resize without augmentation, or no mask")
+            # into the stem's input layout; joints and the ignore mask follow the same map
             B = images.shape[0]
             src_hw = (int(images.shape[1]), int(images.shape[2]))
             if aug_cfg:
@@ -183,6 +177,15 @@ class Trainer:
             x_s2d = augment.augment_u8(images, prm_t, (H, W))
             perm = augment.COCO_FLIP_PERM if joints.shape[1] == 17 else None
             joints = augment.transform_joints(joints, prm_t, W, perm)
+            if mask is not None:
+                # the given mask covers the SOURCE frame in square cells; cells of the output
+                # frame that fall outside it are trained as background (fill = 1)
+                hs = int(self.model_cfg.heatmap_stride)
+                if src_hw[0] % mask.shape[1] or src_hw[0] // mask.shape[1] * mask.shape[2] != src_hw[1]:
+                    raise ValueError(f"mask {tuple(mask.shape[1:])} does not tile the "
+                                     f"{src_hw[0]}x{src_hw[1]} frames in square cells")
+                mask = augment.augment_mask(mask, prm_t, float(src_hw[0] // mask.shape[1]),
+                                            (H // hs, W // hs), float(hs), fill=1)
             images = None
             bb = None     # boxes follow the transformed joints
         kw = {}

@@ -2,7 +2,8 @@
 
 CPU: the NumPy restatement against independent statements (identity map = plain preprocessing,
 integer shifts and mirrors as array slicing, a marker pixel tracked through the joint map).
-GPU: pe_augment_u8_s2d_bf16 / pe_transform_joints_f32 bit for bit against the restatement.
+GPU: pe_augment_u8_s2d_bf16 / pe_transform_joints_f32 / pe_augment_mask_u8 bit for bit against
+the restatement.
 The reference pins only the configuration (test.ipynb:995-1010), not results: parity unpinned.
 """
 import numpy as np
@@ -71,6 +72,28 @@ def test_joint_map_follows_the_image_map():
     assert out[0, 5, 0] == pytest.approx(W - 1 - ((j[0, 6, 0] + 0.5) / 2.0 - 0.5), abs=1e-4)
 
 
+def test_mask_map_follows_the_image_map():
+    # identity map at equal cell sizes copies the mask; a mirror reverses its columns
+    m = synthetic.ignore_mask(2, 8, 12, seed=3, p_ignore=0.4)
+    ident = aug.resize_params(2, (32, 48), (32, 48))
+    assert np.array_equal(oracle.augment_mask(m, ident, 4.0, (8, 12), 4.0), m)
+    flip = ident.copy()
+    flip[:, 4] = 1.0
+    assert np.array_equal(oracle.augment_mask(m, flip, 4.0, (8, 12), 4.0), m[:, :, ::-1])
+    # a crop shifted by two cells reads two cells to the right; what leaves the frame is `fill`
+    shift = ident.copy()
+    shift[:, 2] = 8.0
+    out = oracle.augment_mask(m, shift, 4.0, (8, 12), 4.0, fill=7)
+    assert np.array_equal(out[:, :, :10], m[:, :, 2:]) and np.all(out[:, :, 10:] == 7)
+    # the mask lands where the image lands: a 2x downscale of a frame whose ignored region is the
+    # left half keeps the left half ignored
+    half = np.ones((1, 16, 16), np.uint8)
+    half[:, :, :8] = 0
+    down = aug.resize_params(1, (64, 64), (32, 32))
+    out = oracle.augment_mask(half, down, 4.0, (8, 8), 4.0)
+    assert np.all(out[:, :, :4] == 0) and np.all(out[:, :, 4:] == 1)
+
+
 def test_random_params_respect_the_configured_ranges():
     prm = aug.random_params(2000, (480, 640), (320, 320), (0.5, 2.0), True, True, seed=3)
     z = (640 / 320) / prm[:, 0]
@@ -95,6 +118,24 @@ def test_hip_augment_matches_oracle_bit_for_bit(cfg):
     want = to.space_to_depth16(oracle.augment_u8(img, prm, (H, W), MEAN, STD))
     assert got.shape == (B, H // 2, W // 2, 16)
     assert np.array_equal(got.float().cpu().numpy(), want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cfg", [(4, 480, 640, 8, 256, 192, 4), (3, 96, 64, 4, 64, 96, 4),
+                                 (2, 37, 53, 1, 320, 320, 8), (5, 64, 64, 16, 32, 32, 1)])
+def test_hip_mask_warp_matches_oracle_bit_for_bit(cfg):
+    B, Hs, Ws, ss, H, W, st = cfg
+    Hms, Wms = -(-Hs // ss), -(-Ws // ss)
+    m = synthetic.ignore_mask(B, Hms, Wms, seed=B, p_ignore=0.3)
+    prm = aug.random_params(B, (Hs, Ws), (H, W), (0.5, 2.0), True, True, seed=11)
+    for fill in (1, 0, 255):
+        got = aug.augment_mask(torch.from_numpy(m).cuda(), torch.from_numpy(prm).cuda(), float(ss),
+                               (H // st, W // st), float(st), fill=fill)
+        want = oracle.augment_mask(m, prm, float(ss), (H // st, W // st), float(st), fill=fill)
+        assert got.dtype == torch.uint8 and np.array_equal(got.cpu().numpy(), want)
+    with pytest.raises(RuntimeError, match="strides"):
+        aug.augment_mask(torch.from_numpy(m).cuda(), torch.from_numpy(prm).cuda(), 0.0,
+                         (H // st, W // st), float(st))
 
 
 @pytest.mark.gpu

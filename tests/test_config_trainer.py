@@ -118,8 +118,8 @@ def test_trainer_resizes_and_augments_raw_frames():
 @pytest.mark.gpu
 def test_notebook_flow_with_the_reference_augmentation_config():
     """Trainer(cfg).get_features_labels_data() -> train_step(features, labels) with the
-    reference's own train_config (flip, crop, scale jitter: test.ipynb:995-997): the generator
-    leaves the ignore mask out, because a mask is tied to the frame it was drawn on."""
+    reference's own train_config (flip, crop, scale jitter: test.ipynb:995-997); the ignore mask
+    (`labels['masks']`, test.ipynb:949) is warped with the frames."""
     cfg = {"train_config": {"batch_size": 4, "preprocess": {"image_resize": [64, 96]},
                             "augmentation": {"flip_left_right": True, "random_crop": True,
                                              "scale_range": [0.5, 2.0]}},
@@ -128,9 +128,19 @@ def test_notebook_flow_with_the_reference_augmentation_config():
     tr.build_model(seed=5)
     losses = []
     for features, labels in tr.get_features_labels_data(num_batches=3):
-        assert "masks" not in labels and labels["heatmaps"].shape == (4, 16, 24, 17)
+        assert labels["masks"].shape == (4, 16, 24) and labels["heatmaps"].shape == (4, 16, 24, 17)
         losses.append(tr.train_step(features, labels).item())
     assert all(np.isfinite(losses))
+    # the mask reaches the loss: ignoring every cell of the source frame leaves only what the
+    # augmentation maps from outside the frame (trained as background), so the loss drops
+    step, tr.global_step = tr.global_step, 0
+    full = tr.train_step(features, labels).item()
+    tr.global_step = 0
+    none = tr.train_step(features, dict(labels, masks=torch.zeros_like(labels["masks"]))).item()
+    tr.global_step = step
+    assert 0.0 <= none < full
+    with pytest.raises(ValueError, match="square cells"):
+        tr.train_step(features, dict(labels, masks=labels["masks"][:, :, :5].contiguous()))
     # predict folds the constants once per parameter change, not on every call
     f0 = tr.net.scale["stem"].clone()
     tr.predict(features["images"])
