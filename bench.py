@@ -485,8 +485,10 @@ class Train(Workload):
 
         self.net = TrainablePoseResNet(device)
         self.net.load_state(model.init_state(self.net.specs, seed=3))
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        if multi:
             self.net.enable_data_parallel(32 << 20)
+        self.host_replay = not multi and os.environ.get("PE_HOST_REPLAY", "0") == "1"
         macs, _, _ = flops.forward_macs(256, 192)
         self.flops_per_step = 3 * 2.0 * macs * self.batch   # backward = 2 x forward
         rank = dist.get_rank() if dist.is_initialized() else 0
@@ -496,7 +498,8 @@ class Train(Workload):
         self.mask = torch.from_numpy(synthetic.ignore_mask(self.batch, H, W, seed=4 + rank)).to(device)
 
     def step(self, i):
-        self.net.train_step(self.imgs, self.joints, self.mask, lr=1e-3)
+        self.net.train_step(self.imgs, self.joints, self.mask, lr=1e-3,
+                            host_replay=self.host_replay)
 
     def roofline(self, kern_ms):
         ach = self.flops_per_step / (kern_ms * 1e-3) / 1e12
@@ -557,6 +560,9 @@ class HRNetTrain(Workload):
         # PE_HIP_GRAPH=1 (one GPU only): replay the forward/loss/backward pass as a captured HIP
         # graph.  Measured slower than eager launches on this stack (44.5 vs 39.3 ms), so off.
         self.hip_graph = not multi and os.environ.get("PE_HIP_GRAPH") == "1"
+        # PE_HOST_REPLAY (one GPU only): enqueue the pass from the call list recorded on the
+        # first step instead of walking the Python graph
+        self.host_replay = not multi and os.environ.get("PE_HOST_REPLAY", "0") == "1"
         self.flops_per_step = 3 * 2.0 * hrnet.forward_macs(self.net.spec, 384, 288) * self.batch
         rank = dist.get_rank() if dist.is_initialized() else 0
         self.imgs = torch.from_numpy(synthetic.images_u8(self.batch, 384, 288, seed=1 + rank)).to(device)
@@ -565,7 +571,8 @@ class HRNetTrain(Workload):
         self.mask = torch.from_numpy(synthetic.ignore_mask(self.batch, 96, 72, seed=4 + rank)).to(device)
 
     def step(self, i):
-        self.net.train_step(self.imgs, self.joints, self.mask, lr=1e-3, hip_graph=self.hip_graph)
+        self.net.train_step(self.imgs, self.joints, self.mask, lr=1e-3, hip_graph=self.hip_graph,
+                            host_replay=self.host_replay)
 
     def roofline(self, kern_ms):
         ach = self.flops_per_step / (kern_ms * 1e-3) / 1e12
@@ -620,6 +627,9 @@ class MobileNetTrain(Workload):
         if multi:
             self.net.enable_data_parallel(32 << 20)
         self.hip_graph = not multi and os.environ.get("PE_HIP_GRAPH") == "1"
+        # PE_HOST_REPLAY (one GPU only): enqueue the pass from the call list recorded on the
+        # first step instead of walking the Python graph
+        self.host_replay = not multi and os.environ.get("PE_HOST_REPLAY", "0") == "1"
         self.flops_per_step = 3 * 2.0 * mb.forward_macs(320, 320, K_JOINTS, len(mb.COCO_PAIRS)) \
             * self.batch
         rank = dist.get_rank() if dist.is_initialized() else 0
@@ -628,7 +638,8 @@ class MobileNetTrain(Workload):
                                                         seed=2 + rank)).to(device)
 
     def step(self, i):
-        self.net.train_step(self.imgs, self.joints, None, lr=1e-3, hip_graph=self.hip_graph)
+        self.net.train_step(self.imgs, self.joints, None, lr=1e-3, hip_graph=self.hip_graph,
+                            host_replay=self.host_replay)
 
     def roofline(self, kern_ms):
         ach = self.flops_per_step / (kern_ms * 1e-3) / 1e12

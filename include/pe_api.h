@@ -47,6 +47,31 @@ const char* pe_last_error(void);
 int32_t pe_device_count(void);
 
 /* ------------------------------------------------------------------------
+ * Launch tape: a recorded call list for steps whose shapes and buffers do not change.
+ * Replaces nothing in the reference, whose session loop (train.py, absent; test.ipynb:1060
+ * drives it) re-runs a compiled TensorFlow graph per step: this is the same idea for this
+ * library's launches.  Between pe_tape_begin and pe_tape_end every kernel (and memset, and
+ * pe_stream_wait_stream) that the calling thread enqueues through this library is executed as
+ * usual AND stored with a copy of its arguments; pe_tape_replay enqueues records
+ * [first, first + count) again, on the streams and with the pointers they were recorded with,
+ * at the cost of one hipLaunchKernel each.  The caller keeps every buffer the recorded calls
+ * named alive and at the same address, and replays whatever it enqueued itself between the
+ * recorded calls (pe_tape_length tells where in the tape it stood).  Entry points whose
+ * arguments change from call to call (the optimizer's step number, pe_allreduce_bucket) are
+ * left outside the recorded region.  One tape may record per thread at a time.
+ * ------------------------------------------------------------------------ */
+typedef void* pe_tape_t;
+int32_t pe_tape_begin(void);
+/* Records stored so far on the recording tape, or -1 when none is recording. */
+int64_t pe_tape_length(void);
+int32_t pe_tape_end(pe_tape_t* tape);
+int32_t pe_tape_replay(pe_tape_t tape, int64_t first, int64_t count);
+int32_t pe_tape_destroy(pe_tape_t tape);
+/* `waiter` waits for everything enqueued on `waited` so far (event record + stream wait);
+ * recorded on a tape like a launch. */
+int32_t pe_stream_wait_stream(pe_stream_t waiter, pe_stream_t waited);
+
+/* ------------------------------------------------------------------------
  * a1. Heat-map peak decode.
  * Replaces: the heat-map -> keypoint step of inference.py / utils/ops.py
  * (PoseEstimation.pyproj:28,37; both absent).  The notebook's nearest call is

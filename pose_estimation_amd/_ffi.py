@@ -35,6 +35,12 @@ SIGNATURES = {
     "pe_version": (c_int32, []),
     "pe_last_error": (c_char_p, []),
     "pe_device_count": (c_int32, []),
+    "pe_tape_begin": (c_int32, []),
+    "pe_tape_length": (c_int64, []),
+    "pe_tape_end": (c_int32, [c_void_p]),
+    "pe_tape_replay": (c_int32, [c_void_p, c_int64, c_int64]),
+    "pe_tape_destroy": (c_int32, [c_void_p]),
+    "pe_stream_wait_stream": (c_int32, [c_void_p, c_void_p]),
     "pe_decode_f32": (
         c_int32,
         [c_void_p, c_int32, c_int32, c_int32, c_int32, c_int64, c_int64, c_int64, c_int64,

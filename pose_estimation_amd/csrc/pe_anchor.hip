@@ -278,8 +278,7 @@ extern "C" int32_t pe_anchor_assign_f32(const float* anchors, int32_t A, const f
     PE_REQUIRE(aligned(anchors, 16) && aligned(regs, 16), PE_E_INVALID,
                "%s: anchors and regs must be 16-byte aligned", what);
     PE_REQUIRE(ignore_iou > 0.0f, PE_E_INVALID, "%s: ignore_iou must be positive", what);
-    anchor_assign_kernel<<<(unsigned)B, 256, 0, as_stream(stream)>>>(
-        anchors, A, boxes, box_classes, G, pos_iou, ignore_iou, classes, weights, regs, match);
+    pe::launch(anchor_assign_kernel, (unsigned)B, 256, 0, as_stream(stream), anchors, A, boxes, box_classes, G, pos_iou, ignore_iou, classes, weights, regs, match);
     return check_launch(what);
 }
 
@@ -303,13 +302,13 @@ extern "C" int32_t pe_box_loss_fwd_bwd(const float* logit, const float* reg_pred
     hipStream_t st = as_stream(stream);
     int32_t* npos = static_cast<int32_t*>(workspace);
     float* partial = reinterpret_cast<float*>(npos + B);
-    box_count_kernel<<<(unsigned)B, 256, 0, st>>>(classes, weights, A, npos);
+    pe::launch(box_count_kernel, (unsigned)B, 256, 0, st, classes, weights, A, npos);
     int32_t rc = check_launch("pe_box_loss_fwd_bwd(count)");
     if (rc != PE_OK) return rc;
-    box_loss_kernel<<<(unsigned)B, 256, 0, st>>>(logit, reg_pred, classes, weights, regs, B, A,
+    pe::launch(box_loss_kernel, (unsigned)B, 256, 0, st, logit, reg_pred, classes, weights, regs, B, A,
                                                  reg_weight, npos, partial, grad_logit, grad_reg);
     rc = check_launch("pe_box_loss_fwd_bwd(loss)");
     if (rc != PE_OK) return rc;
-    box_loss_finish_kernel<<<1, 64, 0, st>>>(partial, npos, B, reg_weight, loss4);
+    pe::launch(box_loss_finish_kernel, 1, 64, 0, st, partial, npos, B, reg_weight, loss4);
     return check_launch("pe_box_loss_fwd_bwd(finish)");
 }

@@ -198,8 +198,7 @@ extern "C" int32_t pe_augment_mask_u8(const uint8_t* mask_in, int32_t B, int32_t
     const long total = (long)B * Hm * Wm;
     PE_REQUIRE(total < 0x7fffffffL && (long)B * Hms * Wms < 0x7fffffffL, PE_E_UNSUPPORTED,
                "%s: too many cells", what);
-    augment_mask_kernel<<<(unsigned)((total + 255) / 256), 256, 0, as_stream(stream)>>>(
-        mask_in, B, Hms, Wms, src_stride, params_device, Hm, Wm, stride, fill, mask_out);
+    pe::launch(augment_mask_kernel, (unsigned)((total + 255) / 256), 256, 0, as_stream(stream), mask_in, B, Hms, Wms, src_stride, params_device, Hm, Wm, stride, fill, mask_out);
     return check_launch(what);
 }
 
@@ -221,8 +220,7 @@ extern "C" int32_t pe_augment_u8_s2d_bf16(const uint8_t* img, int32_t B, int32_t
         nm.mean[c] = mean3[c];
         nm.inv_std[c] = 1.0f / std3[c];
     }
-    augment_s2d_kernel<<<(unsigned)((npix2 + 255) / 256), 256, 0, as_stream(stream)>>>(
-        img, B, Hs, Ws, params_device, H / 2, W / 2, nm, static_cast<uint4*>(x_s2d));
+    pe::launch(augment_s2d_kernel, (unsigned)((npix2 + 255) / 256), 256, 0, as_stream(stream), img, B, Hs, Ws, params_device, H / 2, W / 2, nm, static_cast<uint4*>(x_s2d));
     return check_launch(what);
 }
 
@@ -244,7 +242,6 @@ extern "C" int32_t pe_transform_joints_f32(const float* joints_in, int32_t B, in
             perm.to[k] = (int16_t)flip_perm_host[k];
         }
     }
-    transform_joints_kernel<<<(unsigned)((B * K + 255) / 256), 256, 0, as_stream(stream)>>>(
-        joints_in, B, K, params_device, W, perm, joints_out);
+    pe::launch(transform_joints_kernel, (unsigned)((B * K + 255) / 256), 256, 0, as_stream(stream), joints_in, B, K, params_device, W, perm, joints_out);
     return check_launch(what);
 }

@@ -661,8 +661,7 @@ extern "C" int32_t pe_bn_finalize_bf16(const void* workspace, int32_t rows, int6
                "pe_bn_finalize_bf16: give both running buffers or neither");
     const BnFwdOut o{mean, rstd, scale, shift, running_mean, running_var};
     const float unbias = M > 1 ? (float)((double)M / (double)(M - 1)) : 1.0f;
-    bn_fwd_finalize_kernel<<<(C + kFoldCh - 1) / kFoldCh, 256, 0, as_stream(stream)>>>(
-        static_cast<const float*>(workspace), rows, C, (float)(1.0 / (double)M), unbias, gamma, beta,
+    pe::launch(bn_fwd_finalize_kernel, (C + kFoldCh - 1) / kFoldCh, 256, 0, as_stream(stream), static_cast<const float*>(workspace), rows, C, (float)(1.0 / (double)M), unbias, gamma, beta,
         eps, momentum, o);
     return check_launch("pe_bn_finalize_bf16");
 }
@@ -717,8 +716,7 @@ extern "C" int32_t pe_bn_finalize_apply_bf16(const void* workspace, int32_t rows
     const int nfold = (C + kFoldCh - 1) / kFoldCh;
     const long nchunk = M * (C / 8);
     const unsigned grid = (unsigned)nfold + fused_apply_blocks(nchunk, C / 8);
-    bn_fwd_fused_kernel<<<grid, 256, 0, as_stream(stream)>>>(
-        static_cast<const float*>(workspace), rows, C, (float)(1.0 / (double)M), unbias, gamma, beta,
+    pe::launch(bn_fwd_fused_kernel, grid, 256, 0, as_stream(stream), static_cast<const float*>(workspace), rows, C, (float)(1.0 / (double)M), unbias, gamma, beta,
         eps, momentum, o, nfold, sync, sync_take(sync, nfold), static_cast<const uint16_t*>(z),
         nchunk, C / 8,
         static_cast<const uint16_t*>(residual), relu, static_cast<uint16_t*>(y));
@@ -740,13 +738,12 @@ extern "C" int32_t pe_bn_stats_bf16(const void* z, int64_t M, int32_t C, const f
     const BnGeom g = bn_geom(M, C);
     float* partial = static_cast<float*>(workspace);
     hipStream_t st = as_stream(stream);
-    bn_reduce_kernel<0><<<g.nblk, 256, (size_t)g.rl * 2 * C * sizeof(float), st>>>(
-        static_cast<const uint16_t*>(z), nullptr, nullptr, nullptr, nullptr, 0.0f, M, C, g, partial);
+    pe::launch(bn_reduce_kernel<0>, g.nblk, 256, (size_t)g.rl * 2 * C * sizeof(float), st, static_cast<const uint16_t*>(z), nullptr, nullptr, nullptr, nullptr, 0.0f, M, C, g, partial);
     rc = check_launch("pe_bn_stats_bf16(reduce)");
     if (rc != PE_OK) return rc;
     const BnFwdOut o{mean, rstd, scale, shift, running_mean, running_var};
     const float unbias = M > 1 ? (float)((double)M / (double)(M - 1)) : 1.0f;
-    bn_fwd_finalize_kernel<<<(C + kFoldCh - 1) / kFoldCh, 256, 0, st>>>(partial, g.nblk, C,
+    pe::launch(bn_fwd_finalize_kernel, (C + kFoldCh - 1) / kFoldCh, 256, 0, st, partial, g.nblk, C,
                                                            (float)(1.0 / (double)M), unbias, gamma,
                                                            beta, eps, momentum, o);
     return check_launch("pe_bn_stats_bf16(finalize)");
@@ -764,8 +761,7 @@ extern "C" int32_t pe_bn_stats_apply_bf16(const void* z, int64_t M, int32_t C,
     PE_REQUIRE(z && workspace, PE_E_INVALID, "pe_bn_stats_apply_bf16: NULL pointer");
     PE_REQUIRE(aligned(z, 16), PE_E_INVALID, "pe_bn_stats_apply_bf16: z not 16-byte aligned");
     const BnGeom g = bn_geom(M, C);
-    bn_reduce_kernel<0><<<g.nblk, 256, (size_t)g.rl * 2 * C * sizeof(float), as_stream(stream)>>>(
-        static_cast<const uint16_t*>(z), nullptr, nullptr, nullptr, nullptr, 0.0f, M, C, g,
+    pe::launch(bn_reduce_kernel<0>, g.nblk, 256, (size_t)g.rl * 2 * C * sizeof(float), as_stream(stream), static_cast<const uint16_t*>(z), nullptr, nullptr, nullptr, nullptr, 0.0f, M, C, g,
         static_cast<float*>(workspace));
     rc = check_launch("pe_bn_stats_apply_bf16(reduce)");
     if (rc != PE_OK) return rc;
@@ -784,8 +780,7 @@ extern "C" int32_t pe_bn_apply_bf16(const void* z, int64_t M, int32_t C, const f
                    aligned(shift, 16),
                PE_E_INVALID, "pe_bn_apply_bf16: tensors must be 16-byte aligned");
     const long nchunk = M * (C / 8);
-    bn_apply_kernel<<<ew_grid(nchunk), 256, 0, as_stream(stream)>>>(
-        static_cast<const uint16_t*>(z), nchunk, C / 8, scale, shift,
+    pe::launch(bn_apply_kernel, ew_grid(nchunk), 256, 0, as_stream(stream), static_cast<const uint16_t*>(z), nchunk, C / 8, scale, shift,
         static_cast<const uint16_t*>(residual), relu, static_cast<uint16_t*>(y));
     return check_launch("pe_bn_apply_bf16");
 }
@@ -815,31 +810,28 @@ extern "C" int32_t pe_bn_bwd_bf16(const void* da, const void* a, int32_t relu, c
     float* coefB = coefA + C;
     float* coefC = coefB + C;
     hipStream_t st = as_stream(stream);
-    bn_reduce_kernel<1><<<g.nblk, 256, (size_t)g.rl * 2 * C * sizeof(float), st>>>(
-        static_cast<const uint16_t*>(z), static_cast<const uint16_t*>(da),
+    pe::launch(bn_reduce_kernel<1>, g.nblk, 256, (size_t)g.rl * 2 * C * sizeof(float), st, static_cast<const uint16_t*>(z), static_cast<const uint16_t*>(da),
         static_cast<const uint16_t*>(a), act_scale, act_shift, act_hi, M, C, g, partial);
     rc = check_launch("pe_bn_bwd_bf16(reduce)");
     if (rc != PE_OK) return rc;
     if (sync != nullptr) {   // finalize and element-wise pass in one launch
         const int nfold = (C + kFoldCh - 1) / kFoldCh;
         const long nch = M * (C / 8);
-        bn_bwd_fused_kernel<<<(unsigned)nfold + fused_apply_blocks(nch, C / 8), 256, 0, st>>>(
-            partial, g.nblk, C, (float)(1.0 / (double)M), gamma, mean, rstd, dgamma, dbeta, coefA,
+        pe::launch(bn_bwd_fused_kernel, (unsigned)nfold + fused_apply_blocks(nch, C / 8), 256, 0, st, partial, g.nblk, C, (float)(1.0 / (double)M), gamma, mean, rstd, dgamma, dbeta, coefA,
             coefB, coefC, frozen != 0, nfold, sync, sync_take(sync, nfold),
             static_cast<const uint16_t*>(da),
             static_cast<const uint16_t*>(a), static_cast<const uint16_t*>(z), nch, C / 8, act_hi,
             act_scale, act_shift, static_cast<uint16_t*>(dz), static_cast<uint16_t*>(dmasked));
         return check_launch("pe_bn_bwd_bf16(fused)");
     }
-    bn_bwd_finalize_kernel<<<(C + kFoldCh - 1) / kFoldCh, 256, 0, st>>>(partial, g.nblk, C,
+    pe::launch(bn_bwd_finalize_kernel, (C + kFoldCh - 1) / kFoldCh, 256, 0, st, partial, g.nblk, C,
                                                            (float)(1.0 / (double)M), gamma, mean,
                                                            rstd, dgamma, dbeta, coefA, coefB, coefC,
                                                            frozen != 0);
     rc = check_launch("pe_bn_bwd_bf16(finalize)");
     if (rc != PE_OK) return rc;
     const long nchunk = M * (C / 8);
-    bn_bwd_apply_kernel<<<ew_grid(nchunk), 256, 0, st>>>(
-        static_cast<const uint16_t*>(da), static_cast<const uint16_t*>(a),
+    pe::launch(bn_bwd_apply_kernel, ew_grid(nchunk), 256, 0, st, static_cast<const uint16_t*>(da), static_cast<const uint16_t*>(a),
         static_cast<const uint16_t*>(z), nchunk, C / 8, mean, coefA, coefB, coefC, act_hi,
         act_scale, act_shift, static_cast<uint16_t*>(dz), static_cast<uint16_t*>(dmasked));
     return check_launch("pe_bn_bwd_bf16(apply)");
@@ -868,23 +860,20 @@ extern "C" int32_t pe_bn_bwd_from_partials_bf16(const void* g, const void* z, in
     if (sync != nullptr) {   // one launch; g is already masked: no activation operand
         const int nfold = (C + kFoldCh - 1) / kFoldCh;
         const long nch = M * (C / 8);
-        bn_bwd_fused_kernel<<<(unsigned)nfold + fused_apply_blocks(nch, C / 8), 256, 0, st>>>(
-            partial, rows, C, (float)(1.0 / (double)M), gamma, mean, rstd, dgamma, dbeta, coefA,
+        pe::launch(bn_bwd_fused_kernel, (unsigned)nfold + fused_apply_blocks(nch, C / 8), 256, 0, st, partial, rows, C, (float)(1.0 / (double)M), gamma, mean, rstd, dgamma, dbeta, coefA,
             coefB, coefC, frozen != 0, nfold, sync, sync_take(sync, nfold),
             static_cast<const uint16_t*>(g), nullptr,
             static_cast<const uint16_t*>(z), nch, C / 8, INFINITY, nullptr, nullptr,
             static_cast<uint16_t*>(dz), nullptr);
         return check_launch("pe_bn_bwd_from_partials_bf16(fused)");
     }
-    bn_bwd_finalize_kernel<<<(C + kFoldCh - 1) / kFoldCh, 256, 0, st>>>(
-        partial, rows, C, (float)(1.0 / (double)M), gamma, mean, rstd, dgamma, dbeta, coefA, coefB,
+    pe::launch(bn_bwd_finalize_kernel, (C + kFoldCh - 1) / kFoldCh, 256, 0, st, partial, rows, C, (float)(1.0 / (double)M), gamma, mean, rstd, dgamma, dbeta, coefA, coefB,
         coefC, frozen != 0);
     rc = check_launch("pe_bn_bwd_from_partials_bf16(finalize)");
     if (rc != PE_OK) return rc;
     const long nchunk = M * (C / 8);
     // g is already masked: no activation operand
-    bn_bwd_apply_kernel<<<ew_grid(nchunk), 256, 0, st>>>(
-        static_cast<const uint16_t*>(g), nullptr, static_cast<const uint16_t*>(z), nchunk, C / 8,
+    pe::launch(bn_bwd_apply_kernel, ew_grid(nchunk), 256, 0, st, static_cast<const uint16_t*>(g), nullptr, static_cast<const uint16_t*>(z), nchunk, C / 8,
         mean, coefA, coefB, coefC, INFINITY, nullptr, nullptr, static_cast<uint16_t*>(dz), nullptr);
     return check_launch("pe_bn_bwd_from_partials_bf16(apply)");
 }
@@ -895,7 +884,7 @@ extern "C" int32_t pe_bn_fold_f32(const pe_bn_fold_job* jobs_device, int32_t njo
     PE_REQUIRE(jobs_device != nullptr && njobs > 0, PE_E_INVALID,
                "pe_bn_fold_f32: NULL job table or negative count");
     PE_REQUIRE(eps >= 0.0f && isfinite(eps), PE_E_INVALID, "pe_bn_fold_f32: eps must be >= 0");
-    bn_fold_kernel<<<(unsigned)njobs, 256, 0, as_stream(stream)>>>(jobs_device, eps);
+    pe::launch(bn_fold_kernel, (unsigned)njobs, 256, 0, as_stream(stream), jobs_device, eps);
     return check_launch("pe_bn_fold_f32");
 }
 
@@ -904,7 +893,7 @@ extern "C" size_t pe_bn_sync_bytes(void) { return (size_t)kBnSyncInts * sizeof(i
 extern "C" int32_t pe_bn_sync_init(int32_t* sync, pe_stream_t stream) {
     PE_REQUIRE(sync != nullptr && aligned(sync, 128), PE_E_INVALID,
                "pe_bn_sync_init: sync must be a 128-byte aligned device pointer");
-    const hipError_t e = hipMemsetAsync(sync, 0, pe_bn_sync_bytes(), as_stream(stream));
+    const hipError_t e = pe::memset_async(sync, 0, pe_bn_sync_bytes(), as_stream(stream));
     PE_REQUIRE(e == hipSuccess, PE_E_HIP, "pe_bn_sync_init: %s", hipGetErrorString(e));
     std::lock_guard<std::mutex> lock(g_sync_mutex);
     g_sync_count[sync] = 0;

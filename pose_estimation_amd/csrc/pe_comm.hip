@@ -152,8 +152,7 @@ extern "C" int32_t pe_grad_pack_bf16(const float* src, void* dst_bf16, int64_t n
     PE_REQUIRE(n > 0 && src && dst_bf16, PE_E_INVALID, "pe_grad_pack_bf16: NULL pointer or n < 0");
     PE_REQUIRE(aligned(src, 16) && aligned(dst_bf16, 16), PE_E_INVALID,
                "pe_grad_pack_bf16: pointers must be 16-byte aligned");
-    pack_bf16_kernel<<<cast_grid(n), 256, 0, as_stream(stream)>>>(
-        src, static_cast<uint16_t*>(dst_bf16), n);
+    pe::launch(pack_bf16_kernel, cast_grid(n), 256, 0, as_stream(stream), src, static_cast<uint16_t*>(dst_bf16), n);
     return check_launch("pe_grad_pack_bf16");
 }
 
@@ -164,8 +163,7 @@ extern "C" int32_t pe_grad_unpack_bf16(const void* src_bf16, float* dst, int64_t
                "pe_grad_unpack_bf16: NULL pointer or n < 0");
     PE_REQUIRE(aligned(src_bf16, 16) && aligned(dst, 16), PE_E_INVALID,
                "pe_grad_unpack_bf16: pointers must be 16-byte aligned");
-    unpack_bf16_kernel<<<cast_grid(n), 256, 0, as_stream(stream)>>>(
-        static_cast<const uint16_t*>(src_bf16), dst, n);
+    pe::launch(unpack_bf16_kernel, cast_grid(n), 256, 0, as_stream(stream), static_cast<const uint16_t*>(src_bf16), dst, n);
     return check_launch("pe_grad_unpack_bf16");
 }
 
@@ -221,9 +219,9 @@ extern "C" int32_t pe_allreduce_bucket(pe_comm* comm, void* buf, int64_t n, int3
         long blocks = (n + 255) / 256;
         if (blocks > 4096) blocks = 4096;
         if (dtype == PE_DTYPE_F32)
-            scale_kernel<false><<<(unsigned)blocks, 256, 0, st>>>(buf, n, scale);
+            pe::launch(scale_kernel<false>, (unsigned)blocks, 256, 0, st, buf, n, scale);
         else
-            scale_kernel<true><<<(unsigned)blocks, 256, 0, st>>>(buf, n, host_bf16_float(scale));
+            pe::launch(scale_kernel<true>, (unsigned)blocks, 256, 0, st, buf, n, host_bf16_float(scale));
         return check_launch("pe_allreduce_bucket(scale)");
     }
     if (scale != 1.0f) {

@@ -46,7 +46,64 @@ inline bool aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_
     } while (0)
 
 #ifdef __HIPCC__
+#include <tuple>
+#include <utility>
+
 namespace pe {
+
+// ---- launch tape --------------------------------------------------------------------------
+// Every kernel of the library is enqueued through pe::launch.  While a tape is recording on
+// the calling thread (pe_tape_begin .. pe_tape_end) each launch is also stored with a copy of
+// its arguments, so that the same sequence can be enqueued again by pe_tape_replay without any
+// of the host work that led to it (argument checks, plan choice, the caller's own code).
+struct TapeRec {
+    virtual void fire() = 0;
+    virtual ~TapeRec() {}
+};
+bool tape_recording();
+void tape_push(TapeRec* r);
+
+template <class... P>
+struct KernelRec final : TapeRec {
+    void (*k)(P...);
+    dim3 g, b;
+    unsigned lds;
+    hipStream_t st;
+    std::tuple<P...> a;
+    void* ptr[sizeof...(P) ? sizeof...(P) : 1];
+    template <class... A>
+    KernelRec(void (*k_)(P...), dim3 g_, dim3 b_, unsigned l_, hipStream_t s_, A&&... x)
+        : k(k_), g(g_), b(b_), lds(l_), st(s_), a(std::forward<A>(x)...) {
+        fill(std::index_sequence_for<P...>());
+    }
+    template <size_t... I>
+    void fill(std::index_sequence<I...>) {
+        ((ptr[I] = const_cast<void*>(static_cast<const void*>(&std::get<I>(a)))), ...);
+    }
+    void fire() override {
+        (void)hipLaunchKernel(reinterpret_cast<const void*>(k), g, b, ptr, lds, st);
+    }
+};
+
+struct MemsetRec final : TapeRec {
+    void* dst;
+    int value;
+    size_t bytes;
+    hipStream_t st;
+    MemsetRec(void* d, int v, size_t n, hipStream_t s) : dst(d), value(v), bytes(n), st(s) {}
+    void fire() override { (void)hipMemsetAsync(dst, value, bytes, st); }
+};
+
+template <class... P, class... A>
+inline void launch(void (*k)(P...), dim3 g, dim3 b, size_t lds, hipStream_t st, A&&... a) {
+    if (tape_recording()) tape_push(new KernelRec<P...>(k, g, b, (unsigned)lds, st, a...));
+    k<<<g, b, lds, st>>>(a...);
+}
+
+inline hipError_t memset_async(void* dst, int value, size_t bytes, hipStream_t st) {
+    if (tape_recording()) tape_push(new MemsetRec(dst, value, bytes, st));
+    return hipMemsetAsync(dst, value, bytes, st);
+}
 
 // Native 16-byte vector types: the non-temporal load/store builtins accept only these.
 typedef float f32x4 __attribute__((ext_vector_type(4)));

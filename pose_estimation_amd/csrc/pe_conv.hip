@@ -392,8 +392,7 @@ extern "C" int32_t pe_preprocess_u8_s2d_bf16(const uint8_t* img, int32_t B, int3
     PE_REQUIRE(aligned(x_s2d, 16), PE_E_INVALID, "pe_preprocess_u8_s2d_bf16: output misaligned");
     const long npix2 = (long)B * (H / 2) * (W / 2);
     PE_REQUIRE(npix2 < 0x7fffffffL, PE_E_UNSUPPORTED, "pe_preprocess_u8_s2d_bf16: too many pixels");
-    preprocess_s2d_kernel<<<(unsigned)((npix2 + 255) / 256), 256, 0, as_stream(stream)>>>(
-        img, npix2, H / 2, W / 2, mean3[0], mean3[1], mean3[2], 1.0f / std3[0], 1.0f / std3[1],
+    pe::launch(preprocess_s2d_kernel, (unsigned)((npix2 + 255) / 256), 256, 0, as_stream(stream), img, npix2, H / 2, W / 2, mean3[0], mean3[1], mean3[2], 1.0f / std3[0], 1.0f / std3[1],
         1.0f / std3[2], static_cast<uint4*>(x_s2d));
     return check_launch("pe_preprocess_u8_s2d_bf16");
 }
@@ -407,7 +406,6 @@ extern "C" int32_t pe_maxpool3x3s2_fwd_bf16(const void* x, int32_t B, int32_t H,
     PE_REQUIRE(aligned(x, 16) && aligned(y, 16) && aligned(idx, 8), PE_E_INVALID,
                "pe_maxpool3x3s2_fwd_bf16: misaligned");
     const long total = (long)B * (H / 2) * (W / 2) * (C / 8);
-    maxpool3x3s2_kernel<<<(unsigned)((total + 255) / 256), 256, 0, as_stream(stream)>>>(
-        static_cast<const uint16_t*>(x), B, H, W, C, static_cast<uint16_t*>(y), idx);
+    pe::launch(maxpool3x3s2_kernel, (unsigned)((total + 255) / 256), 256, 0, as_stream(stream), static_cast<const uint16_t*>(x), B, H, W, C, static_cast<uint16_t*>(y), idx);
     return check_launch("pe_maxpool3x3s2_fwd_bf16");
 }

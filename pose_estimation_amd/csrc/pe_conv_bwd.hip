@@ -326,7 +326,7 @@ static int32_t conv2d_bwd_data_impl(const pe_conv_desc* d, const void* dy, const
         PE_REQUIRE(residual == nullptr, PE_E_UNSUPPORTED,
                    "pe_conv2d_bwd_data_bf16: residual needs every input parity to have a tap");
         PE_REQUIRE(dx != nullptr, PE_E_INVALID, "pe_conv2d_bwd_data_bf16: NULL dx");
-        const hipError_t e = hipMemsetAsync(dx, 0, (size_t)d->B * d->H * d->W * d->Cin * 2, st);
+        const hipError_t e = pe::memset_async(dx, 0, (size_t)d->B * d->H * d->W * d->Cin * 2, st);
         PE_REQUIRE(e == hipSuccess, PE_E_HIP, "pe_conv2d_bwd_data_bf16: memset: %s",
                    hipGetErrorString(e));
     }
@@ -651,8 +651,7 @@ extern "C" int32_t pe_transpose_weights_bf16(const void* in, int32_t A, int32_t 
                "pe_transpose_weights_bf16: bad sizes");
     PE_REQUIRE(T <= 65535, PE_E_UNSUPPORTED, "pe_transpose_weights_bf16: too many taps");
     dim3 grid((C + 63) / 64, (A + 63) / 64, T);
-    transpose_w_kernel<<<grid, 256, 0, as_stream(stream)>>>(
-        static_cast<const uint16_t*>(in), A, T, C, static_cast<uint16_t*>(out), slots, apitch, t0);
+    pe::launch(transpose_w_kernel, grid, 256, 0, as_stream(stream), static_cast<const uint16_t*>(in), A, T, C, static_cast<uint16_t*>(out), slots, apitch, t0);
     return check_launch("pe_transpose_weights_bf16");
 }
 
@@ -661,7 +660,7 @@ extern "C" int32_t pe_transpose_weights_batched_bf16(const pe_transpose_job* job
                                                      pe_stream_t stream) {
     PE_REQUIRE(jobs_device != nullptr && njobs > 0 && total_tiles > 0, PE_E_INVALID,
                "pe_transpose_weights_batched_bf16: empty job table");
-    transpose_w_batched_kernel<<<(unsigned)total_tiles, 256, 0, as_stream(stream)>>>(jobs_device,
+    pe::launch(transpose_w_batched_kernel, (unsigned)total_tiles, 256, 0, as_stream(stream), jobs_device,
                                                                                     njobs);
     return check_launch("pe_transpose_weights_batched_bf16");
 }
@@ -677,8 +676,7 @@ extern "C" int32_t pe_maxpool3x3s2_bwd_bf16(const uint8_t* idx, const void* dy, 
     const long total = (long)B * H * W * (C / 8);
     long blocks = (total + 255) / 256;
     if (blocks > 256 * 32) blocks = 256 * 32;
-    maxpool3x3s2_bwd_kernel<<<(unsigned)blocks, 256, 0, as_stream(stream)>>>(
-        idx, static_cast<const uint16_t*>(dy), B, H, W, C, static_cast<uint16_t*>(dx));
+    pe::launch(maxpool3x3s2_bwd_kernel, (unsigned)blocks, 256, 0, as_stream(stream), idx, static_cast<const uint16_t*>(dy), B, H, W, C, static_cast<uint16_t*>(dx));
     return check_launch("pe_maxpool3x3s2_bwd_bf16");
 }
 
@@ -699,11 +697,10 @@ extern "C" int32_t pe_final_grad_prepare_bf16(const float* g_nchw, int32_t B, in
         PE_REQUIRE(once == hipSuccess, PE_E_HIP, "pe_final_grad_prepare_bf16: LDS opt-in: %s",
                    hipGetErrorString(once));
     }
-    final_grad_prepare_kernel<<<(unsigned)((npix + 255) / 256), 256, lds, as_stream(stream)>>>(
-        g_nchw, npix, K, HW, Kpad, static_cast<uint16_t*>(out_nhwc));
+    pe::launch(final_grad_prepare_kernel, (unsigned)((npix + 255) / 256), 256, lds, as_stream(stream), g_nchw, npix, K, HW, Kpad, static_cast<uint16_t*>(out_nhwc));
     const int32_t rc = check_launch("pe_final_grad_prepare_bf16");
     if (rc != PE_OK || dbias == nullptr) return rc;
-    bias_grad_kernel<<<(unsigned)K, 1024, 0, as_stream(stream)>>>(g_nchw, B, K, HW, dbias);
+    pe::launch(bias_grad_kernel, (unsigned)K, 1024, 0, as_stream(stream), g_nchw, B, K, HW, dbias);
     return check_launch("pe_final_grad_prepare_bf16 (bias)");
 }
 
@@ -717,6 +714,6 @@ extern "C" int32_t pe_mul_f32(float* a, const float* b, int64_t n, pe_stream_t s
     PE_REQUIRE(a && b, PE_E_INVALID, "pe_mul_f32: NULL pointer");
     long blocks = (n + 255) / 256;
     if (blocks > 4096) blocks = 4096;
-    mul_f32_kernel<<<(unsigned)blocks, 256, 0, as_stream(stream)>>>(a, b, n);
+    pe::launch(mul_f32_kernel, (unsigned)blocks, 256, 0, as_stream(stream), a, b, n);
     return check_launch("pe_mul_f32");
 }

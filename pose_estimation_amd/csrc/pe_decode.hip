@@ -198,22 +198,22 @@ extern "C" int32_t pe_decode_f32(const float* hm, int32_t B, int32_t K, int32_t 
     if (contig && (n % 4) == 0 && aligned(hm, 16)) {
         const int per_lane = (n / 4 + 63) / 64;
         if (per_lane <= 4) {
-            decode_contig_kernel<4><<<grid, 256, 0, st>>>(hm, (int)nmaps, H, W, refine, out);
+            pe::launch(decode_contig_kernel<4>, grid, 256, 0, st, hm, (int)nmaps, H, W, refine, out);
         } else if (per_lane <= 8) {
-            decode_contig_kernel<8><<<grid, 256, 0, st>>>(hm, (int)nmaps, H, W, refine, out);
+            pe::launch(decode_contig_kernel<8>, grid, 256, 0, st, hm, (int)nmaps, H, W, refine, out);
         } else if (per_lane <= 12) {
-            decode_contig_kernel<12><<<grid, 256, 0, st>>>(hm, (int)nmaps, H, W, refine, out);
+            pe::launch(decode_contig_kernel<12>, grid, 256, 0, st, hm, (int)nmaps, H, W, refine, out);
         } else {
-            decode_contig_kernel<16><<<grid, 256, 0, st>>>(hm, (int)nmaps, H, W, refine, out);
+            pe::launch(decode_contig_kernel<16>, grid, 256, 0, st, hm, (int)nmaps, H, W, refine, out);
         }
         return check_launch("pe_decode_f32(contiguous)");
     }
     const bool nhwc = (sK == 1 && sW == K && sH == (int64_t)W * K && K <= 128);
     if (nhwc) {
-        decode_nhwc_kernel<<<(unsigned)B, 256, 256 * 8, st>>>(hm, K, H, W, sB, refine, out);
+        pe::launch(decode_nhwc_kernel, (unsigned)B, 256, 256 * 8, st, hm, K, H, W, sB, refine, out);
         return check_launch("pe_decode_f32(nhwc)");
     }
-    decode_strided_kernel<<<grid, 256, 0, st>>>(hm, (int)nmaps, K, H, W, sB, sK, sH, sW, refine,
+    pe::launch(decode_strided_kernel, grid, 256, 0, st, hm, (int)nmaps, K, H, W, sB, sK, sH, sW, refine,
                                                 out);
     return check_launch("pe_decode_f32(strided)");
 }

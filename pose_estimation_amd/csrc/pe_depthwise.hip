@@ -399,15 +399,13 @@ extern "C" int32_t pe_depthwise3x3_bwd_data_bf16(const void* dy, int32_t B, int3
         const int ntx = dilation * (((W + dilation - 1) / dilation + DW_TX - 1) / DW_TX);
         const long threads = (long)B * nty * ntx * (C / 4);
         PE_REQUIRE((threads + 255) / 256 < 0x7fffffffL, PE_E_UNSUPPORTED, "%s: grid too large", what);
-        depthwise3x3_s1_kernel<<<(unsigned)((threads + 255) / 256), 256, 0, as_stream(stream)>>>(
-            static_cast<const uint16_t*>(dy), B, H, W, C, dilation, static_cast<const uint16_t*>(w),
+        pe::launch(depthwise3x3_s1_kernel, (unsigned)((threads + 255) / 256), 256, 0, as_stream(stream), static_cast<const uint16_t*>(dy), B, H, W, C, dilation, static_cast<const uint16_t*>(w),
             nullptr, nullptr, 0, static_cast<uint16_t*>(dx), nty, ntx, 1);
         return check_launch(what);
     }
     long blocks = (total + 255) / 256;
     if (blocks > 256 * 64) blocks = 256 * 64;
-    depthwise3x3_bwd_data_kernel<<<(unsigned)blocks, 256, 0, as_stream(stream)>>>(
-        static_cast<const uint16_t*>(dy), B, H, W, C, stride, dilation,
+    pe::launch(depthwise3x3_bwd_data_kernel, (unsigned)blocks, 256, 0, as_stream(stream), static_cast<const uint16_t*>(dy), B, H, W, C, stride, dilation,
         static_cast<const uint16_t*>(w), static_cast<uint16_t*>(dx), Ho, Wo);
     return check_launch(what);
 }
@@ -441,13 +439,11 @@ extern "C" int32_t pe_depthwise3x3_bwd_weight_bf16(const void* x, const void* dy
     PE_REQUIRE((size_t)nblk * 9 * C * sizeof(float) <= workspace_bytes, PE_E_INVALID,
                "%s: workspace too small", what);
     hipStream_t st = as_stream(stream);
-    depthwise3x3_bwd_weight_kernel<<<nblk, 256, (size_t)rl * 9 * C * sizeof(float), st>>>(
-        static_cast<const uint16_t*>(x), static_cast<const uint16_t*>(dy), B, H, W, C, stride,
+    pe::launch(depthwise3x3_bwd_weight_kernel, nblk, 256, (size_t)rl * 9 * C * sizeof(float), st, static_cast<const uint16_t*>(x), static_cast<const uint16_t*>(dy), B, H, W, C, stride,
         dilation, Ho, Wo, cells, rl, static_cast<float*>(workspace));
     int32_t rc2 = check_launch(what);
     if (rc2 != PE_OK) return rc2;
-    depthwise3x3_bwd_weight_fold_kernel<<<(9 * C + 3) / 4, 256, 0, st>>>(
-        static_cast<const float*>(workspace), nblk, 9 * C, dw);
+    pe::launch(depthwise3x3_bwd_weight_fold_kernel, (9 * C + 3) / 4, 256, 0, st, static_cast<const float*>(workspace), nblk, 9 * C, dw);
     return check_launch(what);
 }
 
@@ -482,15 +478,13 @@ extern "C" int32_t pe_depthwise3x3_fwd_bf16(const void* x, int32_t B, int32_t H,
         const int ntx = dilation * (((W + dilation - 1) / dilation + DW_TX - 1) / DW_TX);
         const long threads = (long)B * nty * ntx * (C / 4);
         PE_REQUIRE((threads + 255) / 256 < 0x7fffffffL, PE_E_UNSUPPORTED, "%s: grid too large", what);
-        depthwise3x3_s1_kernel<<<(unsigned)((threads + 255) / 256), 256, 0, as_stream(stream)>>>(
-            static_cast<const uint16_t*>(x), B, H, W, C, dilation, static_cast<const uint16_t*>(w),
+        pe::launch(depthwise3x3_s1_kernel, (unsigned)((threads + 255) / 256), 256, 0, as_stream(stream), static_cast<const uint16_t*>(x), B, H, W, C, dilation, static_cast<const uint16_t*>(w),
             scale, shift, relu, static_cast<uint16_t*>(y), nty, ntx, nt ? 2 : 0);
         return check_launch(what);
     }
     long blocks = (total + 255) / 256;
     if (blocks > 256 * 64) blocks = 256 * 64;
-    depthwise3x3_kernel<<<(unsigned)blocks, 256, 0, as_stream(stream)>>>(
-        static_cast<const uint16_t*>(x), B, H, W, C, stride, dilation,
+    pe::launch(depthwise3x3_kernel, (unsigned)blocks, 256, 0, as_stream(stream), static_cast<const uint16_t*>(x), B, H, W, C, stride, dilation,
         static_cast<const uint16_t*>(w), scale, shift, relu, static_cast<uint16_t*>(y), Ho, Wo);
     return check_launch(what);
 }

@@ -98,8 +98,7 @@ extern "C" int32_t pe_fuse_upsample_add_bf16(const void* base, int32_t n_low,
         a.shift[i] = s;
     }
     const long total = (long)B * H * W * (C / 8);
-    fuse_upsample_add_kernel<<<(unsigned)((total + 255) / 256), 256, 0, as_stream(stream)>>>(
-        a, B, H, W, C / 8, relu, static_cast<uint4*>(y));
+    pe::launch(fuse_upsample_add_kernel, (unsigned)((total + 255) / 256), 256, 0, as_stream(stream), a, B, H, W, C / 8, relu, static_cast<uint4*>(y));
     return check_launch(what);
 }
 
@@ -221,15 +220,14 @@ extern "C" int32_t pe_fuse_upsample_add_bwd_bf16(const void* dy, const void* y, 
         PE_REQUIRE(s >= 1 && s <= 5 && H % (1 << s) == 0 && W % (1 << s) == 0, PE_E_INVALID,
                    "%s: map size %dx%d is not a multiple of the upsampling factor 2^%d", what, H, W, s);
         const long total = (long)B * (H >> s) * (W >> s) * C8;
-        block_sum_kernel<<<(unsigned)((total + 255) / 256), 256, 0, st>>>(
-            static_cast<const uint4*>(dy), static_cast<const uint4*>(y), B, H, W, C8, s,
+        pe::launch(block_sum_kernel, (unsigned)((total + 255) / 256), 256, 0, st, static_cast<const uint4*>(dy), static_cast<const uint4*>(y), B, H, W, C8, s,
             static_cast<uint4*>(dlow_host[i]));
         const int32_t rc = check_launch(what);
         if (rc != PE_OK) return rc;
     }
     if (dbase) {
         const long n = (long)B * H * W * C8;
-        relu_mask_kernel<<<stream_grid(n), 256, 0, st>>>(static_cast<const uint4*>(dy),
+        pe::launch(relu_mask_kernel, stream_grid(n), 256, 0, st, static_cast<const uint4*>(dy),
                                                         static_cast<const uint4*>(y), n,
                                                         static_cast<uint4*>(dbase));
         return check_launch(what);
@@ -243,7 +241,6 @@ extern "C" int32_t pe_add_bf16(const void* a, const void* b, int64_t n, void* ou
                "pe_add_bf16: NULL pointer or element count not a positive multiple of 8");
     PE_REQUIRE(aligned(a, 16) && aligned(b, 16) && aligned(out, 16), PE_E_INVALID,
                "pe_add_bf16: tensors must be 16-byte aligned");
-    add_bf16_kernel<<<stream_grid(n / 8), 256, 0, as_stream(stream)>>>(
-        static_cast<const uint4*>(a), static_cast<const uint4*>(b), n / 8, static_cast<uint4*>(out));
+    pe::launch(add_bf16_kernel, stream_grid(n / 8), 256, 0, as_stream(stream), static_cast<const uint4*>(a), static_cast<const uint4*>(b), n / 8, static_cast<uint4*>(out));
     return check_launch("pe_add_bf16");
 }

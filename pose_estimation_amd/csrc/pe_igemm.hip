@@ -637,8 +637,7 @@ static int32_t launch_cfg(IgemmParams& p, long maxM, hipStream_t st, const char*
             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)once;
     }
-    igemm_kernel<BM, BN, WM, PIPE, PF, MINB, MASK, WN, FAST>
-        <<<grid, WM * WN * 64, lds, st>>>(p);
+    pe::launch(igemm_kernel<BM, BN, WM, PIPE, PF, MINB, MASK, WN, FAST>, grid, WM * WN * 64, lds, st, p);
     return check_launch(what);
 }
 

@@ -206,18 +206,17 @@ __global__ __launch_bounds__(kReduceWaves * 64) void mse_reduce_kernel(
 int32_t launch_map_sum_reduce(const float* partial, int B, int K, float per_map_scale,
                               float loss_scale, float* per_map, float* loss, hipStream_t st,
                               const char* what) {
-    mse_reduce_kernel<<<1, kReduceWaves * 64, (size_t)K * sizeof(float), st>>>(
-        partial, B, K, per_map_scale, loss_scale, per_map, loss);
+    pe::launch(mse_reduce_kernel, 1, kReduceWaves * 64, (size_t)K * sizeof(float), st, partial, B, K, per_map_scale, loss_scale, per_map, loss);
     return check_launch(what);
 }
 
 template <bool BF16, bool FUSED>
 static void launch_mse(const MseArgs& a, const GaussTable& tab, unsigned grid, hipStream_t st) {
     const bool hm = a.mask != nullptr, hg = a.grad != nullptr;
-    if (hm && hg) mse_map_kernel<BF16, FUSED, true, true><<<grid, 256, 0, st>>>(a, tab);
-    else if (hm) mse_map_kernel<BF16, FUSED, true, false><<<grid, 256, 0, st>>>(a, tab);
-    else if (hg) mse_map_kernel<BF16, FUSED, false, true><<<grid, 256, 0, st>>>(a, tab);
-    else mse_map_kernel<BF16, FUSED, false, false><<<grid, 256, 0, st>>>(a, tab);
+    if (hm && hg) pe::launch(mse_map_kernel<BF16, FUSED, true, true>, grid, 256, 0, st, a, tab);
+    else if (hm) pe::launch(mse_map_kernel<BF16, FUSED, true, false>, grid, 256, 0, st, a, tab);
+    else if (hg) pe::launch(mse_map_kernel<BF16, FUSED, false, true>, grid, 256, 0, st, a, tab);
+    else pe::launch(mse_map_kernel<BF16, FUSED, false, false>, grid, 256, 0, st, a, tab);
 }
 
 }  // namespace pe

@@ -132,7 +132,7 @@ extern "C" int32_t pe_adam_step(float* p, float* m, float* v, const float* grad,
     h.step_size = step_size;
     h.denom_scale = denom_scale;
     h.grad_scale = grad_scale;
-    adam_kernel<<<optim_grid(n), 256, 0, as_stream(stream)>>>(p, m, v, grad, p_bf16, (long)n, h);
+    pe::launch(adam_kernel, optim_grid(n), 256, 0, as_stream(stream), p, m, v, grad, p_bf16, (long)n, h);
     return check_launch("pe_adam_step");
 }
 
@@ -145,7 +145,7 @@ extern "C" int32_t pe_sgd_step(float* p, float* mom, const float* grad, uint16_t
     PE_REQUIRE(p && mom && grad, PE_E_INVALID, "pe_sgd_step: NULL arena pointer");
     PE_REQUIRE(aligned(p, 16) && aligned(mom, 16) && aligned(grad, 16) && aligned(p_bf16, 8),
                PE_E_INVALID, "pe_sgd_step: arenas must be 16-byte aligned (bf16 copy: 8)");
-    sgd_kernel<<<optim_grid(n), 256, 0, as_stream(stream)>>>(p, mom, grad, p_bf16, (long)n, lr,
+    pe::launch(sgd_kernel, optim_grid(n), 256, 0, as_stream(stream), p, mom, grad, p_bf16, (long)n, lr,
                                                             momentum, grad_scale);
     return check_launch("pe_sgd_step");
 }

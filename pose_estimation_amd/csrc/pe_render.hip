@@ -112,7 +112,7 @@ extern "C" int32_t pe_render_targets_f32(const float* joints, int32_t B, int32_t
     const bool contig = (tW == 1 && tH == W && tK == n && tB == (int64_t)K * n);
     if (contig && (W % 4) == 0 && aligned(target, 16)) {
         const unsigned grid = (unsigned)((nmaps + 3) / 4);
-        render_contig_kernel<<<grid, 256, 0, st>>>(joints, (int)nmaps, H, W, stride, radius, tab,
+        pe::launch(render_contig_kernel, grid, 256, 0, st, joints, (int)nmaps, H, W, stride, radius, tab,
                                                    target, weight);
         return check_launch("pe_render_targets_f32(contiguous)");
     }
@@ -120,7 +120,7 @@ extern "C" int32_t pe_render_targets_f32(const float* joints, int32_t B, int32_t
     int64_t blocks = (total + 255) / 256;
     if (blocks > 8192) blocks = 8192;
     const int k_fastest = (tK < tW) ? 1 : 0;
-    render_strided_kernel<<<(unsigned)blocks, 256, 0, st>>>(joints, B, K, H, W, stride, radius,
+    pe::launch(render_strided_kernel, (unsigned)blocks, 256, 0, st, joints, B, K, H, W, stride, radius,
                                                             tab, target, tB, tK, tH, tW,
                                                             k_fastest, weight);
     return check_launch("pe_render_targets_f32(strided)");

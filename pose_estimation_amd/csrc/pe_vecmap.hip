@@ -233,13 +233,12 @@ extern "C" int32_t pe_render_vecmaps_f32(const float* joints, int32_t B, int32_t
     const int64_t n = (int64_t)H * W;
     const bool contig = (sW == 1 && sH == W && sC == n && sB == (int64_t)C * n);
     if (contig && (W % 4) == 0 && aligned(vec, 16)) {
-        vec_render_contig_kernel<<<(unsigned)((nmaps + 3) / 4), 256, 0, st>>>(
-            joints, K, pt, C, (int)nmaps, H, W, stride, radius, vec);
+        pe::launch(vec_render_contig_kernel, (unsigned)((nmaps + 3) / 4), 256, 0, st, joints, K, pt, C, (int)nmaps, H, W, stride, radius, vec);
         return check_launch("pe_render_vecmaps_f32(contiguous)");
     }
     int64_t blocks = (nmaps * n + 255) / 256;
     if (blocks > 8192) blocks = 8192;
-    vec_render_strided_kernel<<<(unsigned)blocks, 256, 0, st>>>(joints, B, K, pt, C, H, W, stride,
+    pe::launch(vec_render_strided_kernel, (unsigned)blocks, 256, 0, st, joints, B, K, pt, C, H, W, stride,
                                                                 radius, vec, sB, sC, sH, sW,
                                                                 sC < sW ? 1 : 0);
     return check_launch("pe_render_vecmaps_f32(strided)");
@@ -296,7 +295,7 @@ extern "C" int32_t pe_vecmap_loss_fwd_bwd(const void* pred, int32_t pred_dtype, 
     hipStream_t st = as_stream(stream);
     const unsigned grid = (unsigned)((nmaps + 3) / 4);
     const bool hm = mask != nullptr, hg = grad != nullptr;
-#define PE_VL(BF_, M_, G_) vec_loss_kernel<BF_, M_, G_><<<grid, 256, 0, st>>>(a)
+#define PE_VL(BF_, M_, G_) pe::launch(vec_loss_kernel<BF_, M_, G_>, grid, 256, 0, st, a)
     if (bf16) {
         if (hm && hg) PE_VL(true, true, true);
         else if (hm) PE_VL(true, true, false);

@@ -421,7 +421,7 @@ int32_t wgrad_launch(WgradParams& p, void* workspace, size_t workspace_bytes, hi
                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                    \
             (void)once;                                                                   \
         }                                                                                 \
-        wgrad_kernel<FLAT_, NS_><<<grid, 256, lds, st>>>(p);                              \
+        pe::launch(wgrad_kernel<FLAT_, NS_>, grid, 256, lds, st, p);                              \
     }
     if (flat) {
         if (ns == 4) PE_WG(true, 4) else if (ns == 3) PE_WG(true, 3)
@@ -435,13 +435,13 @@ int32_t wgrad_launch(WgradParams& p, void* workspace, size_t workspace_bytes, hi
     if (rc != PE_OK || splits == 1) return rc;
     const long groups = P >> 2;
     if (splits >= 64) {
-        wgrad_reduce_kernel<16><<<(unsigned)((groups + 15) / 16), 256, 0, st>>>(p.slab, (int)splits,
+        pe::launch(wgrad_reduce_kernel<16>, (unsigned)((groups + 15) / 16), 256, 0, st, p.slab, (int)splits,
                                                                               P, p.dw);
     } else if (splits >= 8) {
-        wgrad_reduce_kernel<4><<<(unsigned)((groups + 63) / 64), 256, 0, st>>>(p.slab, (int)splits,
+        pe::launch(wgrad_reduce_kernel<4>, (unsigned)((groups + 63) / 64), 256, 0, st, p.slab, (int)splits,
                                                                              P, p.dw);
     } else {
-        wgrad_reduce_kernel<1><<<(unsigned)((groups + 255) / 256), 256, 0, st>>>(p.slab, (int)splits,
+        pe::launch(wgrad_reduce_kernel<1>, (unsigned)((groups + 255) / 256), 256, 0, st, p.slab, (int)splits,
                                                                               P, p.dw);
     }
     return check_launch(what);

@@ -27,6 +27,7 @@ import torch
 
 from . import nn as pnn
 from . import ops
+from . import replay
 from .parallel import GradBucketer
 
 BF16 = torch.bfloat16
@@ -160,7 +161,7 @@ class TrainGraph:
             if m is not None:
                 self.masks[L.name] = m.to(dev)
         self._tplan: Optional[pnn.TransposePlan] = None
-        self._ws: Optional[torch.Tensor] = None
+        self._ws: Dict[int, torch.Tensor] = {}
         self.tape: list = []
         self.training = False
         self.bucketer: Optional[GradBucketer] = None
@@ -185,7 +186,10 @@ class TrainGraph:
         # short one (a pointwise conv from 64 channels) the separate pass measured faster
         self.fuse_min_k = int(os.environ.get("PE_FUSE_MIN_K", "256"))
         self._pending_wg: list = []
+        # set by a network that runs branches of its forward pass on streams of their own
+        self.multi_stream = False
         self._step_graphs: Dict[tuple, "StepGraph"] = {}
+        self._recorded: Dict[tuple, "replay.RecordedPass"] = {}
 
     # ------------------------------------------------------------------ parameters
     def view(self, arena: torch.Tensor, name: str) -> torch.Tensor:
@@ -291,10 +295,16 @@ class TrainGraph:
         self.refresh_transposes()
 
     def _workspace_for(self, M: int, C: int) -> torch.Tensor:
+        """Scratch for batch-norm partial sums: one buffer per stream, since a producer's rows
+        must survive until the finalize behind it on the same stream has read them and branches
+        on streams of their own run side by side."""
         need = pnn.lib().pe_bn_workspace_bytes(M, C)
-        if self._ws is None or self._ws.numel() < need:
-            self._ws = torch.empty(max(need, 1 << 24), dtype=torch.uint8, device=self.device)
-        return self._ws
+        key = torch.cuda.current_stream(self.device).cuda_stream
+        ws = self._ws.get(key)
+        if ws is None or ws.numel() < need:
+            ws = self._ws[key] = torch.empty(max(need, 1 << 24), dtype=torch.uint8,
+                                             device=self.device)
+        return ws
 
     # ------------------------------------------------------------------ forward layers
     def begin(self, training: bool) -> None:
@@ -351,24 +361,25 @@ class TrainGraph:
             return out
         if L.kind == "stem3":
             M = B * H * W
-            z, rows = pnn.stem3x3s2_bnstats(x.t, self.w(L), self._workspace_for(M, L.cout))
+            ws = self._workspace_for(M, L.cout)
+            z, rows = pnn.stem3x3s2_bnstats(x.t, self.w(L), ws)
         else:
             Ho = (H + 2 * L.pad - L.k) // L.stride + 1
             Wo = (W + 2 * L.pad - L.k) // L.stride + 1
             M = B * Ho * Wo
-            z, rows = pnn.conv2d_bnstats(x.t, self.w(L), self._workspace_for(M, L.cout), L.stride,
-                                         L.pad, **kw)
+            ws = self._workspace_for(M, L.cout)
+            z, rows = pnn.conv2d_bnstats(x.t, self.w(L), ws, L.stride, L.pad, **kw)
         if self.freeze_bn:
             r = self.bn_rows[L.name]
             out = Var(pnn.bn_apply(z, r[2], r[3], res_t, act))
         elif self.bn_sync is not None:
-            out = Var(pnn.bn_finalize_apply(self._ws, rows, z, gamma, beta, BN_EPS,
+            out = Var(pnn.bn_finalize_apply(ws, rows, z, gamma, beta, BN_EPS,
                                             self.bn_momentum, self.bn_mean[L.name],
                                             self.bn_var[L.name], self.bn_rows[L.name],
                                             self.bn_sync, res_t, act))
         else:
             _, _, scale, shift = pnn.bn_finalize(
-                self._ws, rows, M, L.cout, gamma, beta, BN_EPS, self.bn_momentum,
+                ws, rows, M, L.cout, gamma, beta, BN_EPS, self.bn_momentum,
                 self.bn_mean[L.name], self.bn_var[L.name], out=self.bn_rows[L.name])
             out = Var(pnn.bn_apply(z, scale, shift, res_t, act))
         if act and residual is None:
@@ -410,7 +421,7 @@ class TrainGraph:
         if side is None:
             yield
             return
-        side.wait_stream(torch.cuda.current_stream(self.device))
+        replay.wait_stream(side, torch.cuda.current_stream(self.device))
         self._keep.extend(tensors)
         with torch.cuda.stream(side):
             yield
@@ -496,6 +507,11 @@ class TrainGraph:
         self.grads.zero_()
         self._done_names = set()
         self._next_layer = len(self.layers) - 1
+        # Backward stays on one stream (plus the weight-gradient stream) even when forward forked
+        # its branches: with the weight gradients already filling the gaps beside the main chain,
+        # running every record on the stream that made it measured no faster (34.4 against
+        # 34.5 ms on the HRNet-W32 step) and slower once the streams outnumber the four
+        # hardware queues (36.9 ms).
         while self.tape:
             rec = self.tape.pop()
             if rec[0] == "head":
@@ -547,7 +563,7 @@ class TrainGraph:
                 out.grad = None
         self._flush_weight_grads()
         if self.wgrad_stream is not None:   # the optimizer reads every gradient
-            torch.cuda.current_stream(self.device).wait_stream(self.wgrad_stream)
+            replay.wait_stream(torch.cuda.current_stream(self.device), self.wgrad_stream)
         self._keep.clear()
 
     # ------------------------------------------------------------------ HIP-graph replay
@@ -567,6 +583,18 @@ class TrainGraph:
         if g is None:
             g = self._step_graphs[key] = StepGraph(self, fn, inputs)
         return g(*inputs)
+
+    def replay_host(self, fn, *inputs: Optional[torch.Tensor]):
+        """Runs fn(*inputs) from a recorded call list (replay.RecordedPass): the launches of the
+        first call are kept by the library and enqueued again without the Python walk that
+        produced them.  Same contract as replay(): static shapes, outputs overwritten by the
+        next call, not with a gradient exchange attached; and not with the one-launch batch
+        norm, whose hand-off counter is an argument that moves from launch to launch."""
+        if self.bucketer is not None:
+            raise RuntimeError("host replay and the bucketed gradient exchange are exclusive")
+        if self.bn_sync is not None:
+            raise RuntimeError("host replay and PE_BN_FUSED=1 are exclusive")
+        return replay.run_recorded(self._recorded, self, fn, inputs)
 
     # ------------------------------------------------------------------ optimizer
     def optimizer_step(self, lr: float, optimizer: str = "adam", beta1: float = 0.9,

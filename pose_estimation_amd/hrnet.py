@@ -29,6 +29,7 @@ import torch
 
 from . import nn as pnn
 from . import ops
+from . import replay
 from .graph import Layer, TrainGraph, Var
 
 BF16 = torch.bfloat16
@@ -368,6 +369,14 @@ class TrainablePoseHRNet(TrainGraph):
         self.heatmap_stride = heatmap_stride
         self._side: List[torch.cuda.Stream] = []
         self.branch_streams = os.environ.get("PE_HRNET_BRANCH_STREAMS", "1") != "0"
+        # training too: the branches of a module on streams of their own in forward (the step is
+        # bound by the GPU, 36.8 -> 34.5 ms; backward stays on one stream, see
+        # TrainGraph.backward).  Activations made on a side stream are read by backward on the
+        # main stream and freed there; the side streams start every module behind the main
+        # stream, so their next allocation is ordered after those readers.  The one-launch batch
+        # norm's hand-off buffer belongs to one stream, so not with it.
+        self.multi_stream = (self.branch_streams and self.bn_sync is None
+                             and os.environ.get("PE_HRNET_TRAIN_STREAMS", "1") != "0")
 
     def _u(self, u: Unit, x, residual=None, relu=None):
         return self.unit(self.by_name[u.name], x, residual,
@@ -379,21 +388,22 @@ class TrainablePoseHRNet(TrainGraph):
         return x
 
     def _module(self, m: Module, xs):
-        if not self.training and self.branch_streams and len(xs) > 1:
-            # inference: the branches on streams of their own, as in PoseHRNet._module (training
-            # is bound by the host's launch rate, where concurrency on the GPU buys nothing)
+        if (not self.training or self.multi_stream) and self.branch_streams and len(xs) > 1:
+            # the branches on streams of their own, as in PoseHRNet._module
             main = torch.cuda.current_stream(self.device)
-            while len(self._side) < len(xs) - 1:
+            nside = len(xs) - 1
+            while len(self._side) < nside:
                 self._side.append(torch.cuda.Stream(self.device))
-            side = self._side[:len(xs) - 1]
+            side = self._side[:nside]
             ys = [None] * len(xs)
+            for st in side:
+                replay.wait_stream(st, main)
             for i in range(len(xs) - 1, 0, -1):
-                side[i - 1].wait_stream(main)
-                with torch.cuda.stream(side[i - 1]):
+                with torch.cuda.stream(side[min(i, nside) - 1]):
                     ys[i] = self._branch(xs[i], m.branches[i])
             ys[0] = self._branch(xs[0], m.branches[0])
             for st in side:
-                main.wait_stream(st)
+                replay.wait_stream(main, st)
         else:
             ys = [self._branch(x, br) for x, br in zip(xs, m.branches)]
         outs = []
@@ -454,11 +464,16 @@ class TrainablePoseHRNet(TrainGraph):
     def train_step(self, images_u8, joints: torch.Tensor, mask: Optional[torch.Tensor] = None,
                    lr: float = 1e-3, optimizer: str = "adam", beta1: float = 0.9,
                    beta2: float = 0.999, eps: float = 1e-8, momentum: float = 0.9,
-                   x_s2d: Optional[torch.Tensor] = None, hip_graph: bool = False):
+                   x_s2d: Optional[torch.Tensor] = None, hip_graph: bool = False,
+                   host_replay: bool = False):
         """One optimisation step; returns (loss [1] device tensor, per_joint [K]).  hip_graph:
-        replay the forward/loss/backward pass as one captured HIP graph (see TrainGraph.replay)."""
+        replay the forward/loss/backward pass as one captured HIP graph (see TrainGraph.replay);
+        host_replay: enqueue it from the call list recorded on the first step
+        (TrainGraph.replay_host)."""
         fn, x = (self._pass, x_s2d) if x_s2d is not None else (self._pass_u8, images_u8)
-        if hip_graph:
+        if host_replay:
+            loss, per_joint = self.replay_host(fn, x, joints, mask)
+        elif hip_graph:
             loss, per_joint = self.replay(fn, x, joints, mask)
         else:
             loss, per_joint = fn(x, joints, mask)

@@ -434,7 +434,7 @@ class TrainablePoseMobileNetV2(TrainGraph):
             vloss, _, vgrad = ops.vecmap_loss_fwd_bwd(out[1], joints, self.pairs, s, self.radius,
                                                       mask)
             grads["vec"] = vgrad
-            loss = loss + vloss
+            loss.add_(vloss)      # in place: a recorded pass cannot repeat an allocation
         if self.det_blocks:
             if det_labels is None:
                 raise ValueError("this network has a detection branch: pass det_labels")
@@ -459,16 +459,18 @@ class TrainablePoseMobileNetV2(TrainGraph):
                    lr: float = 1e-3, optimizer: str = "adam", beta1: float = 0.9,
                    beta2: float = 0.999, eps: float = 1e-8, momentum: float = 0.9,
                    x_s2d: Optional[torch.Tensor] = None, hip_graph: bool = False,
-                   det_labels=None):
+                   det_labels=None, host_replay: bool = False):
         """One optimisation step on heat-map loss + vector-map loss (+ objectness and box loss
         with the detection branch, which needs det_labels = (classes, weights, regs)); returns
         (loss [1] device tensor, per_joint [K]).  hip_graph: replay the forward/loss/backward
-        pass as one captured HIP graph (see TrainGraph.replay)."""
+        pass as one captured HIP graph (see TrainGraph.replay); host_replay: enqueue it from the
+        call list recorded on the first step (TrainGraph.replay_host)."""
         fn, x = (self._pass, x_s2d) if x_s2d is not None else (self._pass_u8, images_u8)
-        if hip_graph:
+        if hip_graph or host_replay:
             if self.det_blocks:
-                raise ValueError("HIP-graph replay is not wired for the detection branch")
-            loss, per_joint = self.replay(fn, x, joints, mask)
+                raise ValueError("replay is not wired for the detection branch")
+            run = self.replay_host if host_replay else self.replay
+            loss, per_joint = run(fn, x, joints, mask)
         else:
             loss, per_joint = fn(x, joints, mask, det_labels)
         self.optimizer_step(lr, optimizer, beta1, beta2, eps, momentum)

@@ -17,6 +17,7 @@ import torch
 
 from . import nn as pnn
 from . import ops
+from . import replay
 from .model import BF16, BN_EPS, ConvSpec, PoseResNet
 from .parallel import GradBucketer
 
@@ -58,6 +59,8 @@ class TrainablePoseResNet(PoseResNet):
         self.bucketer: Optional[GradBucketer] = None
         self.saved: dict = {}
         self._wt_pending = False
+        self._recorded: Dict[tuple, "replay.RecordedPass"] = {}
+        self._keep: list = []
         # backward-data GEMMs mask their result and reduce it for the batch norm below them
         # (PE_FUSE_BN_BWD=0: the separate reduction pass, for comparison)
         self.fuse_bn_bwd = os.environ.get("PE_FUSE_BN_BWD", "1") != "0"
@@ -120,8 +123,8 @@ class TrainablePoseResNet(PoseResNet):
     def _join_transposes(self) -> None:
         """The re-pack a training step left running on the side stream is done before anything
         on the current stream touches the backward-data weights."""
-        if self._wt_pending:
-            torch.cuda.current_stream(self.device).wait_stream(self.wgrad_stream)
+        if self._wt_pending or replay.recording():   # a recorded pass always waits
+            replay.wait_stream(torch.cuda.current_stream(self.device), self.wgrad_stream)
             self._wt_pending = False
 
     def refresh_transposes(self) -> None:
@@ -335,9 +338,14 @@ class TrainablePoseResNet(PoseResNet):
         if side is None:
             yield
             return
-        side.wait_stream(torch.cuda.current_stream(self.device))
-        for t in tensors:
-            t.record_stream(side)
+        replay.wait_stream(side, torch.cuda.current_stream(self.device))
+        if replay.recording() or os.environ.get("PE_RESNET_KEEP") == "1":
+            # a recorded pass replays the allocator's decisions too: memory the side stream
+            # reads must not be reused on the main stream before backward has joined the two
+            self._keep.extend(tensors)
+        else:
+            for t in tensors:
+                t.record_stream(side)
         with torch.cuda.stream(side):
             yield
 
@@ -387,21 +395,45 @@ class TrainablePoseResNet(PoseResNet):
             pnn.mul_(gw, self.stem_mask)
             self._done(stem)
         if self.wgrad_stream is not None:   # the optimizer reads every gradient
-            torch.cuda.current_stream(self.device).wait_stream(self.wgrad_stream)
+            replay.wait_stream(torch.cuda.current_stream(self.device), self.wgrad_stream)
+        self._keep.clear()
 
     # ------------------------------------------------------------------ one optimisation step
-    def train_step(self, images_u8: torch.Tensor, joints: torch.Tensor,
-                   mask: Optional[torch.Tensor] = None, lr: float = 1e-3, optimizer: str = "adam",
-                   beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8,
-                   momentum: float = 0.9, x_s2d: Optional[torch.Tensor] = None):
-        """images uint8 [B,H,W,3] (or None with x_s2d given, see forward_train); joints float32
-        [B,K,3] (x, y, v) in input pixels; mask uint8 [B,H/4,W/4] or None.
-        Returns (loss [1] float32 device tensor, per_joint [K])."""
+    def _pass(self, images_u8, x_s2d, joints, mask):
+        """Forward with batch statistics, loss, backward: fills the gradient arena."""
         hm = self.forward_train(images_u8, x_s2d)
         loss, per_joint, grad, _ = ops.mse_fwd_bwd(hm, joints=joints, mask=mask,
                                                   stride=self.heatmap_stride, sigma=self.sigma,
                                                   radius=self.radius)
         self.backward(grad)
+        self.saved = {}
+        return loss, per_joint
+
+    def replay_host(self, fn, *inputs: Optional[torch.Tensor]):
+        """fn(*inputs) from a recorded call list (replay.RecordedPass): the first call's launches
+        are kept by the library and enqueued again without the Python code that produced them.
+        Static shapes; outputs are overwritten by the next call; not with a gradient exchange
+        attached (its collectives are issued by the host) nor with the one-launch batch norm
+        (its hand-off counter is an argument that moves from launch to launch)."""
+        if self.bucketer is not None:
+            raise RuntimeError("host replay and the bucketed gradient exchange are exclusive")
+        if self.bn_sync is not None:
+            raise RuntimeError("host replay and PE_BN_FUSED=1 are exclusive")
+        return replay.run_recorded(self._recorded, self, fn, inputs)
+
+    def train_step(self, images_u8: torch.Tensor, joints: torch.Tensor,
+                   mask: Optional[torch.Tensor] = None, lr: float = 1e-3, optimizer: str = "adam",
+                   beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8,
+                   momentum: float = 0.9, x_s2d: Optional[torch.Tensor] = None,
+                   host_replay: bool = False):
+        """images uint8 [B,H,W,3] (or None with x_s2d given, see forward_train); joints float32
+        [B,K,3] (x, y, v) in input pixels; mask uint8 [B,H/4,W/4] or None.  host_replay: enqueue
+        the forward/loss/backward pass from the call list recorded on the first step.
+        Returns (loss [1] float32 device tensor, per_joint [K])."""
+        if host_replay:
+            loss, per_joint = self.replay_host(self._pass, images_u8, x_s2d, joints, mask)
+        else:
+            loss, per_joint = self._pass(images_u8, x_s2d, joints, mask)
         scale = 1.0
         if self.bucketer is not None:
             self.bucketer.finish()
@@ -420,11 +452,10 @@ class TrainablePoseResNet(PoseResNet):
         side = self.wgrad_stream if os.environ.get("PE_TRANSPOSE_SIDE", "1") != "0" else None
         if side is not None:
             self._join_transposes()
-            side.wait_stream(torch.cuda.current_stream(self.device))
+            replay.wait_stream(side, torch.cuda.current_stream(self.device))
             with torch.cuda.stream(side):
                 self._tplan_run()
             self._wt_pending = True
         else:
             self.refresh_transposes()
-        self.saved = {}
         return loss, per_joint
