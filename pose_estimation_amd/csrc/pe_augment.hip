@@ -38,72 +38,148 @@ __device__ __forceinline__ uint64_t load_u64_unaligned(const uint8_t* p) {
     return reinterpret_cast<const U64*>(p)->v;
 }
 
-__global__ __launch_bounds__(256) void augment_s2d_kernel(const uint8_t* __restrict__ img, int B,
-                                                          int Hs, int Ws,
-                                                          const float* __restrict__ params, int H2,
-                                                          int W2, AugNorm nm,
-                                                          uint4* __restrict__ out) {
-    const long npix2 = (long)B * H2 * W2;
-    const long t = (long)blockIdx.x * 256 + threadIdx.x;
-    if (t >= npix2) return;
-    const int X = (int)(t % W2);
-    const long r = t / W2;
-    const int Y = (int)(r % H2);
-    const long b = r / H2;
+// value / 255 correctly rounded, in three instructions instead of the dozen of a general
+// division: q = RN(v * y) with y = RN(1/255), the exact residual r = v - 255 q by one fused
+// multiply-add, and q + r y rounded once more.  With y the correctly rounded reciprocal and
+// 255's significand not all ones this is the correctly rounded quotient (Markstein), i.e. the
+// same float as v / 255.0f; tests compare the kernel with NumPy's division bit for bit.
+__device__ __forceinline__ float div255(float v) {
+    const float y = 1.0f / 255.0f;
+    const float q = v * y;
+    const float r = __builtin_fmaf(-q, 255.0f, v);
+    return __builtin_fmaf(r, y, q);
+}
+
+// A workgroup makes a tile of kTileX x kTileY space-to-depth pixels (2 kTileX x 2 kTileY output
+// pixels) of one image.  The bilinear footprint of an output pixel separates into a column part
+// (x0, fx), which depends on x alone, and a row part (y0, fy): the tile's 2 kTileX columns and
+// 2 kTileY rows are worked out once, by the first threads, and shared through LDS, and the image
+// index comes from the grid, so the per-image parameters are scalar loads and no thread divides.
+constexpr int kTileX = 32, kTileY = 8;
+
+__global__ __launch_bounds__(kTileX * kTileY) void augment_s2d_kernel(
+    const uint8_t* __restrict__ img, int Hs, int Ws, const float* __restrict__ params, int H2,
+    int W2, AugNorm nm, uint4* __restrict__ out) {
+    __shared__ int cx0[2 * kTileX], ry0[2 * kTileY];
+    __shared__ float cfx[2 * kTileX], rfy[2 * kTileY];
+    const int b = blockIdx.z;
+    const int tid = threadIdx.x;
     const int W = 2 * W2;
     const float sx = params[b * 5 + 0], sy = params[b * 5 + 1];
     const float tx = params[b * 5 + 2], ty = params[b * 5 + 3];
     const bool flip = params[b * 5 + 4] != 0.0f;
-    const uint8_t* src = img + b * (long)Hs * Ws * 3;
-    float h[12];
-#pragma unroll
-    for (int ry = 0; ry < 2; ++ry) {
-        const int y = 2 * Y + ry;
+    if (tid < 2 * kTileX) {
+        const int x = 2 * kTileX * blockIdx.x + tid;
+        const int xf = flip ? W - 1 - x : x;
+        const float u = ((float)xf + 0.5f) * sx + tx - 0.5f;
+        const float uf = floorf(u);
+        cfx[tid] = u - uf;
+        cx0[tid] = (int)fminf(fmaxf(uf, -1.0e9f), 1.0e9f);
+    } else if (tid < 2 * kTileX + 2 * kTileY) {
+        const int i = tid - 2 * kTileX;
+        const int y = 2 * kTileY * blockIdx.y + i;
         const float v = ((float)y + 0.5f) * sy + ty - 0.5f;
         const float vf = floorf(v);
-        const float fy = v - vf;
-        const int y0 = (int)fminf(fmaxf(vf, -1.0e9f), 1.0e9f);
+        rfy[i] = v - vf;
+        ry0[i] = (int)fminf(fmaxf(vf, -1.0e9f), 1.0e9f);
+    }
+    __syncthreads();
+    const int lx = tid % kTileX, ly = tid / kTileX;
+    const int X = kTileX * blockIdx.x + lx, Y = kTileY * blockIdx.y + ly;
+    if (X >= W2 || Y >= H2) return;
+    const uint8_t* src = img + (long)b * Hs * Ws * 3;
+    const long pitch = (long)Ws * 3;
+    int x0[2], y0[2];
+    float fx[2], fy[2];
+    bool xin[2], yin[2];
 #pragma unroll
-        for (int rx = 0; rx < 2; ++rx) {
-            const int x = 2 * X + rx;
-            const int xf = flip ? W - 1 - x : x;
-            const float u = ((float)xf + 0.5f) * sx + tx - 0.5f;
-            const float uf = floorf(u);
-            const float fx = u - uf;
-            const int x0 = (int)fminf(fmaxf(uf, -1.0e9f), 1.0e9f);
-            // Interior pixels (all four taps in the frame, and the 8 bytes from the left tap on
-            // still inside the row): the two taps of a row are 6 consecutive bytes, fetched by
-            // one unaligned 8-byte load instead of six byte loads.  Same values, same arithmetic.
-            const bool inner = x0 >= 0 && x0 + 3 <= Ws && y0 >= 0 && y0 + 1 < Hs &&
-                               (long)x0 * 3 + 8 <= (long)Ws * 3;
-            float p00[3], p01[3], p10[3], p11[3];
-            if (inner) {
-                const uint8_t* r0 = src + ((long)y0 * Ws + x0) * 3;
-                const uint64_t a0 = load_u64_unaligned(r0);
-                const uint64_t a1 = load_u64_unaligned(r0 + (long)Ws * 3);
+    for (int r = 0; r < 2; ++r) {
+        x0[r] = cx0[2 * lx + r];
+        fx[r] = cfx[2 * lx + r];
+        y0[r] = ry0[2 * ly + r];
+        fy[r] = rfy[2 * ly + r];
+        // Interior footprints (both taps in the frame, and the 8 bytes from the left tap on still
+        // inside the row): the two taps of a row are 6 consecutive bytes, fetched by one
+        // unaligned 8-byte load instead of six byte loads.  Same values, same arithmetic.
+        xin[r] = x0[r] >= 0 && x0[r] + 3 <= Ws && (long)x0[r] * 3 + 8 <= pitch;
+        yin[r] = y0[r] >= 0 && y0[r] + 1 < Hs;
+    }
+    const bool all_inner = xin[0] && xin[1] && yin[0] && yin[1];
+    const long t = ((long)b * H2 + Y) * W2 + X;
+    // A zoomed-out or shifted map leaves whole regions of the output outside the frame: all
+    // sixteen taps are zero there and the block is a constant.  (0 + f*(0 - 0) = +0 whatever f
+    // is, so this is the value the general path computes.)
+    const bool rows_out = (y0[0] + 1 < 0 || y0[0] >= Hs) && (y0[1] + 1 < 0 || y0[1] >= Hs);
+    const bool cols_out = (x0[0] + 1 < 0 || x0[0] >= Ws) && (x0[1] + 1 < 0 || x0[1] >= Ws);
+    if (rows_out || cols_out) {
+        float k[3];
 #pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    p00[c] = (float)(uint32_t)((a0 >> (8 * c)) & 0xffu);
-                    p01[c] = (float)(uint32_t)((a0 >> (8 * (c + 3))) & 0xffu);
-                    p10[c] = (float)(uint32_t)((a1 >> (8 * c)) & 0xffu);
-                    p11[c] = (float)(uint32_t)((a1 >> (8 * (c + 3))) & 0xffu);
-                }
-            } else {
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    p00[c] = aug_tap(src, Hs, Ws, y0, x0, c);
-                    p01[c] = aug_tap(src, Hs, Ws, y0, x0 + 1, c);
-                    p10[c] = aug_tap(src, Hs, Ws, y0 + 1, x0, c);
-                    p11[c] = aug_tap(src, Hs, Ws, y0 + 1, x0 + 1, c);
-                }
-            }
-#pragma unroll
+        for (int c = 0; c < 3; ++c) k[c] = (div255(0.0f) - nm.mean[c]) * nm.inv_std[c];
+        u32x4 lo = {pack_bf16x2_bits(k[0], k[1]), pack_bf16x2_bits(k[2], k[0]),
+                    pack_bf16x2_bits(k[1], k[2]), pack_bf16x2_bits(k[0], k[1])};
+        u32x4 hi = {pack_bf16x2_bits(k[2], k[0]), pack_bf16x2_bits(k[1], k[2]), 0u, 0u};
+        __builtin_nontemporal_store(lo, reinterpret_cast<u32x4*>(out) + 2 * t);
+        __builtin_nontemporal_store(hi, reinterpret_cast<u32x4*>(out) + 2 * t + 1);
+        return;
+    }
+    if (!all_inner) {
+        // Frame borders and whatever the map throws outside the frame: tap by tap, one value at a
+        // time (rolled loops keep this rare path from costing the common one its registers).
+        uint16_t* o = reinterpret_cast<uint16_t*>(out + 2 * t);
+#pragma unroll 1
+        for (int i = 0; i < 4; ++i) {
+            const int ry = i >> 1, rx = i & 1;
+#pragma unroll 1
             for (int c = 0; c < 3; ++c) {
-                const float top = p00[c] + fx * (p01[c] - p00[c]);
-                const float bot = p10[c] + fx * (p11[c] - p10[c]);
-                const float val = top + fy * (bot - top);
-                h[(ry * 2 + rx) * 3 + c] = (val / 255.0f - nm.mean[c]) * nm.inv_std[c];
+                const float p00 = aug_tap(src, Hs, Ws, y0[ry], x0[rx], c);
+                const float p01 = aug_tap(src, Hs, Ws, y0[ry], x0[rx] + 1, c);
+                const float p10 = aug_tap(src, Hs, Ws, y0[ry] + 1, x0[rx], c);
+                const float p11 = aug_tap(src, Hs, Ws, y0[ry] + 1, x0[rx] + 1, c);
+                const float top = p00 + fx[rx] * (p01 - p00);
+                const float bot = p10 + fx[rx] * (p11 - p10);
+                const float val = top + fy[ry] * (bot - top);
+                o[i * 3 + c] = (uint16_t)float_to_bf16_bits((div255(val) - nm.mean[c]) * nm.inv_std[c]);
             }
+        }
+        *reinterpret_cast<uint2*>(o + 12) = make_uint2(0u, 0u);
+        return;
+    }
+    // the common case: eight independent loads in flight per lane
+    uint32_t a[4][4];    // per pixel: low and high words of the upper and of the lower row
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint8_t* r0 = src + (long)y0[i >> 1] * pitch + (long)x0[i & 1] * 3;
+        const uint64_t u0 = load_u64_unaligned(r0);
+        const uint64_t u1 = load_u64_unaligned(r0 + pitch);
+        a[i][0] = (uint32_t)u0;
+        a[i][1] = (uint32_t)(u0 >> 32);
+        a[i][2] = (uint32_t)u1;
+        a[i][3] = (uint32_t)(u1 >> 32);
+    }
+    float h[12];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int ry = i >> 1, rx = i & 1;
+        float p00[3], p01[3], p10[3], p11[3];
+        // bytes 0..2 = left tap, 3..5 = right tap (byte 3 in the low word, 4 and 5 in the high)
+        p00[0] = (float)(a[i][0] & 0xffu);
+        p00[1] = (float)((a[i][0] >> 8) & 0xffu);
+        p00[2] = (float)((a[i][0] >> 16) & 0xffu);
+        p01[0] = (float)(a[i][0] >> 24);
+        p01[1] = (float)(a[i][1] & 0xffu);
+        p01[2] = (float)((a[i][1] >> 8) & 0xffu);
+        p10[0] = (float)(a[i][2] & 0xffu);
+        p10[1] = (float)((a[i][2] >> 8) & 0xffu);
+        p10[2] = (float)((a[i][2] >> 16) & 0xffu);
+        p11[0] = (float)(a[i][2] >> 24);
+        p11[1] = (float)(a[i][3] & 0xffu);
+        p11[2] = (float)((a[i][3] >> 8) & 0xffu);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float top = p00[c] + fx[rx] * (p01[c] - p00[c]);
+            const float bot = p10[c] + fx[rx] * (p11[c] - p10[c]);
+            const float val = top + fy[ry] * (bot - top);
+            h[i * 3 + c] = (div255(val) - nm.mean[c]) * nm.inv_std[c];
         }
     }
     uint4 lo, hi;
@@ -115,8 +191,9 @@ __global__ __launch_bounds__(256) void augment_s2d_kernel(const uint8_t* __restr
     hi.y = pack_bf16x2_bits(h[10], h[11]);
     hi.z = 0u;
     hi.w = 0u;
-    out[2 * t] = lo;
-    out[2 * t + 1] = hi;
+    __builtin_nontemporal_store(*reinterpret_cast<u32x4*>(&lo), reinterpret_cast<u32x4*>(out) + 2 * t);
+    __builtin_nontemporal_store(*reinterpret_cast<u32x4*>(&hi),
+                                reinterpret_cast<u32x4*>(out) + 2 * t + 1);
 }
 
 struct JointPerm {
@@ -220,7 +297,11 @@ extern "C" int32_t pe_augment_u8_s2d_bf16(const uint8_t* img, int32_t B, int32_t
         nm.mean[c] = mean3[c];
         nm.inv_std[c] = 1.0f / std3[c];
     }
-    pe::launch(augment_s2d_kernel, (unsigned)((npix2 + 255) / 256), 256, 0, as_stream(stream), img, B, Hs, Ws, params_device, H / 2, W / 2, nm, static_cast<uint4*>(x_s2d));
+    PE_REQUIRE(B <= 65535, PE_E_UNSUPPORTED, "%s: at most 65535 images per call", what);
+    const dim3 grid((unsigned)((W / 2 + kTileX - 1) / kTileX), (unsigned)((H / 2 + kTileY - 1) / kTileY),
+                    (unsigned)B);
+    pe::launch(augment_s2d_kernel, grid, kTileX * kTileY, 0, as_stream(stream), img, Hs, Ws,
+               params_device, H / 2, W / 2, nm, static_cast<uint4*>(x_s2d));
     return check_launch(what);
 }
 
