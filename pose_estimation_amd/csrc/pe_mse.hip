@@ -149,64 +149,59 @@ __global__ __launch_bounds__(256) void mse_map_kernel(MseArgs a, GaussTable tab)
     if (lane == 0) a.partial[map] = acc;
 }
 
-// Stage 2: per-joint sums over the batch (wave per joint, lanes stride the batch, butterfly),
-// then one thread adds the K joint sums in order.  One workgroup of 16 waves; a lane's loads are
-// issued four at a time (the stage is bound by load latency, not by bytes) and added in batch
-// order, so the result does not depend on the unrolling.
-constexpr int kReduceWaves = 16;
-__global__ __launch_bounds__(kReduceWaves * 64) void mse_reduce_kernel(
+// Stage 2: per-joint sums over the batch, then the K joint sums added in order.  One workgroup
+// of 1024 threads.  partial is [B][K], so consecutive threads take consecutive joints (coalesced
+// reads) and the S = 1024 / K thread slices share the batch: slice s adds rows s, s + S, ... in
+// order, eight independent loads at a time (the stage is bound by load latency, not by bytes),
+// then the slices are added in order.  The order of additions depends on (B, K) alone.
+constexpr int kReduceThreads = 1024;
+__global__ __launch_bounds__(kReduceThreads) void mse_reduce_kernel(
     const float* __restrict__ partial, int B, int K, float joint_scale, float loss_scale,
     float* per_joint, float* loss) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* sums = reinterpret_cast<float*>(smem);
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    // a wave folds up to four joints at a time: their loads are independent and all in flight
-    for (int k0 = wave; k0 < K; k0 += 4 * kReduceWaves) {
-        float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-        int kk[4];
+    float* sums = reinterpret_cast<float*>(smem);   // [K] joint sums
+    float* red = sums + K;                          // [S][Kc] slice sums of the current chunk
+    const int tid = threadIdx.x;
+    const int Kc = K < kReduceThreads ? K : kReduceThreads;   // joints per chunk
+    const int S = kReduceThreads / Kc;
+    const int kl = tid % Kc, sl = tid / Kc;
+    for (int k0 = 0; k0 < K; k0 += Kc) {
+        const int k = k0 + kl;
+        float acc = 0.0f;
+        if (sl < S && k < K) {
+            const float* col = partial + k;
+            int b = sl;
+            for (; b + 7 * S < B; b += 8 * S) {
+                float v[8];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) kk[j] = k0 + j * kReduceWaves;
-        int b = lane;
-        for (; b + 192 < B; b += 256) {
-            float v[4][4];
+                for (int u = 0; u < 8; ++u) v[u] = col[(long)(b + u * S) * K];
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    v[j][u] = kk[j] < K ? partial[(long)(b + 64 * u) * K + kk[j]] : 0.0f;
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int u = 0; u < 4; ++u) acc[j] += v[j][u];
-        }
-        for (; b < B; b += 64) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (kk[j] < K) acc[j] += partial[(long)b * K + kk[j]];
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float t = wave_sum(acc[j]);
-            if (lane == 0 && kk[j] < K) {
-                sums[kk[j]] = t;
-                if (per_joint) per_joint[kk[j]] = t * joint_scale;
+                for (int u = 0; u < 8; ++u) acc += v[u];
             }
+            for (; b < B; b += S) acc += col[(long)b * K];
+            red[sl * Kc + kl] = acc;
         }
+        __syncthreads();
+        if (sl == 0 && k < K) {
+            float t = red[kl];
+            for (int q = 1; q < S; ++q) t += red[q * Kc + kl];
+            sums[k] = t;
+            if (per_joint) per_joint[k] = t * joint_scale;
+        }
+        __syncthreads();
     }
-    __syncthreads();
-    if (wave == 0) {   // lane l adds joints l, l + 64, ... in order, then the butterfly
+    if (tid < 64) {   // lane l adds joints l, l + 64, ... in order, then the butterfly
         float tot = 0.0f;
-        for (int k = lane; k < K; k += 64) tot += sums[k];
+        for (int k = tid; k < K; k += 64) tot += sums[k];
         tot = wave_sum(tot);
-        if (lane == 0) *loss = tot * loss_scale;
+        if (tid == 0) *loss = tot * loss_scale;
     }
 }
 
 int32_t launch_map_sum_reduce(const float* partial, int B, int K, float per_map_scale,
                               float loss_scale, float* per_map, float* loss, hipStream_t st,
                               const char* what) {
-    pe::launch(mse_reduce_kernel, 1, kReduceWaves * 64, (size_t)K * sizeof(float), st, partial, B, K, per_map_scale, loss_scale, per_map, loss);
+    pe::launch(mse_reduce_kernel, 1, kReduceThreads, ((size_t)K + kReduceThreads) * sizeof(float), st, partial, B, K, per_map_scale, loss_scale, per_map, loss);
     return check_launch(what);
 }
 
