@@ -857,6 +857,10 @@ def main() -> None:
         rec = traffic.get(wl.name)
         if rec:
             rl["traffic"] = rec["traffic_bytes_per_launch"]
+            if rl["bound"] == "mfma":
+                # the network steps move enough bytes for HBM to matter as much as the matrix
+                # cores: the measured traffic over this run's step time, against the HBM peak
+                rl["hbm_frac"] = rl["traffic"] / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
         return rl
 
     wl = WORKLOADS[args.workload]()
