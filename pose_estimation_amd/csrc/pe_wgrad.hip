@@ -152,10 +152,40 @@ __global__ __launch_bounds__(256, NS == 1 ? 4 : (NS == 2 ? 2 : 1)) void wgrad_ke
         xoff[t] = frow * WG_ROWB + (((2 * (wave_c * 4 + t) + fsub) ^ fsw) * 16) + fbyte;
     }
 
-    // issues the loads of the K step that starts at pixel mb into `stage`
+    // Output-grid coordinates (image, row, column) of this thread's first staging row at the
+    // first K step.  Its other rows lie 16 pixels apart and the next K step 64 pixels on: both
+    // are reached by adding a constant (image, row, column) step with one carry per digit, so
+    // the K loop holds no division (the two divisions per row and step it replaces cost more
+    // vector-ALU time than the step's 32 MFMAs).  The host keeps B*Ho*Wo and B*Hi*Wi below 2^31.
+    int cb = 0, coy = 0, cox = 0;
+    int s16b = 0, s16y = 0, s16x = 0, s64b = 0, s64y = 0, s64x = 0;
+    if constexpr (!FLAT) {
+        int rem;
+        fast_divmod((int)(ms + rr), HoWo, inv_howo, cb, rem);
+        fast_divmod(rem, p.Wo, inv_wo, coy, cox);
+        s16b = 16 / HoWo;
+        s16y = (16 % HoWo) / p.Wo;
+        s16x = (16 % HoWo) % p.Wo;
+        s64b = 64 / HoWo;
+        s64y = (64 % HoWo) / p.Wo;
+        s64x = (64 % HoWo) % p.Wo;
+    }
+    auto advance = [&](int& b, int& oy, int& ox, int db, int dyy, int dxx) {
+        ox += dxx;
+        const int cx = ox >= p.Wo ? 1 : 0;
+        ox -= cx ? p.Wo : 0;
+        oy += dyy + cx;
+        const int cy = oy >= p.Ho ? 1 : 0;
+        oy -= cy ? p.Ho : 0;
+        b += db + cy;
+    };
+
+    // issues the loads of the K step that starts at pixel mb into `stage`; K steps are issued
+    // in order, one call per step
     auto issue = [&](char* stage, long mb) {
         char* ytile = stage;
         char* xtile = stage + WG_TILE;
+        int b = cb, oy = coy, ox = cox;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const long m = mb + rr + 16 * i;
@@ -166,23 +196,21 @@ __global__ __launch_bounds__(256, NS == 1 ? 4 : (NS == 2 ? 2 : 1)) void wgrad_ke
                 ysrc = (mv && n_ok) ? p.dy + m * p.ldy + nn : zero;
                 xsrc = (mv && c_ok) ? p.x + m * p.Cx + xch : zero;
             } else {
-                int b, rem, oy, ox;
-                fast_divmod((int)m, HoWo, inv_howo, b, rem);
-                fast_divmod(rem, p.Wo, inv_wo, oy, ox);
-                const long opix = (long)b * OHW + (oy * p.osy + p.ooy) * p.OW + ox * p.osx + p.oox;
-                ysrc = (mv && n_ok) ? p.dy + opix * p.ldy + nn : zero;
+                const int opix = b * OHW + (oy * p.osy + p.ooy) * p.OW + ox * p.osx + p.oox;
+                ysrc = (mv && n_ok) ? p.dy + (long)opix * p.ldy + nn : zero;
                 const int iy = oy * p.sy + tdy;
                 const int ix = ox * p.sx + tdx;
                 const bool inb = (unsigned)iy < (unsigned)p.Hi && (unsigned)ix < (unsigned)p.Wi;
-                xsrc = (mv && c_ok && inb)
-                           ? p.x + (((long)b * p.Hi * p.Wi + (long)iy * p.Wi + ix) * p.Cx + xch)
-                           : zero;
+                const int ipix = (b * p.Hi + iy) * p.Wi + ix;
+                xsrc = (mv && c_ok && inb) ? p.x + ((long)ipix * p.Cx + xch) : zero;
+                if (i < 3) advance(b, oy, ox, s16b, s16y, s16x);
             }
             __builtin_amdgcn_global_load_lds((gptr_t)ysrc,
                                              (lptr_t)(ytile + (16 * i + 4 * wid) * WG_ROWB), 16, 0, 0);
             __builtin_amdgcn_global_load_lds((gptr_t)xsrc,
                                              (lptr_t)(xtile + (16 * i + 4 * wid) * WG_ROWB), 16, 0, 0);
         }
+        if constexpr (!FLAT) advance(cb, coy, cox, s64b, s64y, s64x);
     };
     auto multiply = [&](const char* stage) {
         const char* ytile = stage;
@@ -367,6 +395,7 @@ int32_t wgrad_launch(WgradParams& p, void* workspace, size_t workspace_bytes, hi
                "%s: tensors must be 16-byte aligned", what);
     const long M = (long)p.B * p.Ho * p.Wo;
     PE_REQUIRE(M < 0x7fffffffL && (long)p.B * p.OH * p.OW < 0x7fffffffL &&
+                   (long)p.B * p.Hi * p.Wi < 0x7fffffffL &&
                    (long)p.Ho * p.Wo < (1L << 22) && p.B < (1 << 20),
                PE_E_UNSUPPORTED, "%s: pixel counts out of range", what);
     const long ktot = (long)p.T * p.Cin;
