@@ -398,6 +398,29 @@ size_t pe_wgrad_workspace_bytes(int64_t weight_elems);
 int32_t pe_conv2d_bwd_weight_bf16(const pe_conv_desc* d, const void* x, const void* dy,
                                   int32_t ldy, float* dw, void* workspace,
                                   size_t workspace_bytes, pe_stream_t stream);
+
+/* The weight gradients of up to PE_WGRAD_MAX_BATCH convs in one launch plus one fold launch
+ * (model/base_model.py's backward, absent: TensorFlow ran a layer's filter gradient as one op;
+ * at batch 64 a single layer's gradient is microseconds of work inside ~19 us of launch, fill,
+ * drain and fold latency, so the layers whose gradients are due together share a launch).
+ * Each job is what one pe_conv2d_bwd_weight_bf16 call takes; results differ from that call's
+ * only in the order of the pixel splits' sum, which is fixed by the batch's shapes alone.
+ * workspace: pe_wgrad_batched_workspace_bytes(sum over jobs of Cout*KH*KW*Cin) bytes. */
+#define PE_WGRAD_MAX_BATCH 8
+typedef struct pe_wgrad_job {
+    pe_conv_desc desc;
+    const void* x;      /* forward input  [B,H,W,Cin]   bf16 */
+    const void* dy;     /* output gradient [B,Ho,Wo,ldy] bf16 */
+    float* dw;          /* [Cout,KH,KW,Cin] float32, accumulated into */
+    int32_t ldy;
+    int32_t reserved;
+} pe_wgrad_job;
+size_t pe_wgrad_batched_workspace_bytes(int64_t total_weight_elems);
+int32_t pe_conv2d_bwd_weight_batched_bf16(const pe_wgrad_job* jobs, int32_t njobs, void* workspace,
+                                          size_t workspace_bytes, pe_stream_t stream);
+/* The transposed conv's weight gradient: its four output parities are four gradients of equal
+ * size and go out as one batched launch, so the workspace is
+ * pe_wgrad_batched_workspace_bytes(16*Cout*Cin) bytes. */
 int32_t pe_deconv4x4s2_bwd_weight_bf16(int32_t B, int32_t H, int32_t W, int32_t Cin,
                                        int32_t Cout, const void* x, const void* dy,
                                        float* dw_phases, void* workspace,

@@ -141,6 +141,8 @@ SIGNATURES = {
     "pe_conv2d_bwd_weight_bf16": (
         c_int32, [c_void_p, c_void_p, c_void_p, c_int32, c_void_p, c_void_p, c_size_t, c_void_p],
     ),
+    "pe_wgrad_batched_workspace_bytes": (c_size_t, [c_int64]),
+    "pe_conv2d_bwd_weight_batched_bf16": (c_int32, [c_void_p, c_int32, c_void_p, c_size_t, c_void_p]),
     "pe_deconv4x4s2_bwd_weight_bf16": (
         c_int32,
         [c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p, c_void_p,
@@ -247,6 +249,17 @@ class ConvDesc(ctypes.Structure):
 
     _fields_ = [(n, c_int32) for n in ("B", "H", "W", "Cin", "Cout", "KH", "KW", "stride", "pad",
                                        "relu", "out_f32_nchw")]
+
+
+PE_WGRAD_MAX_BATCH = 8
+
+
+class WgradJob(ctypes.Structure):
+    """Mirror of pe_wgrad_job (include/pe_api.h)."""
+
+    _fields_ = [("desc", ConvDesc), ("x", c_void_p), ("dy", c_void_p), ("dw", c_void_p),
+                ("ldy", c_int32), ("reserved", c_int32)]
+
 
 _lib = None
 

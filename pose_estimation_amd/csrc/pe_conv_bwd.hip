@@ -472,21 +472,20 @@ extern "C" int32_t pe_deconv4x4s2_bwd_data_bnmask_bf16(int32_t B, int32_t H, int
     return deconv_bwd_data_impl(B, H, W, Cin, Cout, dy, w_t, g, &mr, stream);
 }
 
-extern "C" int32_t pe_conv2d_bwd_weight_bf16(const pe_conv_desc* d, const void* x, const void* dy,
-                                             int32_t ldy, float* dw, void* workspace,
-                                             size_t workspace_bytes, pe_stream_t stream) {
-    PE_REQUIRE(d != nullptr, PE_E_INVALID, "pe_conv2d_bwd_weight_bf16: NULL descriptor");
+// pe_conv_desc + tensors -> the weight-gradient GEMM's parameters
+static int32_t conv_wgrad_params(const pe_conv_desc* d, const void* x, const void* dy, int32_t ldy,
+                                 float* dw, WgradParams& p, const char* what) {
+    PE_REQUIRE(d != nullptr, PE_E_INVALID, "%s: NULL descriptor", what);
     PE_REQUIRE(d->KH > 0 && d->KW > 0 && d->KH * d->KW <= kMaxTaps, PE_E_UNSUPPORTED,
-               "pe_conv2d_bwd_weight_bf16: filter %dx%d not supported", d->KH, d->KW);
+               "%s: filter %dx%d not supported", what, d->KH, d->KW);
     PE_REQUIRE(d->stride >= 1 && d->pad >= 0 && d->B > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 &&
                    d->Cout > 0,
-               PE_E_INVALID, "pe_conv2d_bwd_weight_bf16: bad sizes");
+               PE_E_INVALID, "%s: bad sizes", what);
     const int Ho = (d->H + 2 * d->pad - d->KH) / d->stride + 1;
     const int Wo = (d->W + 2 * d->pad - d->KW) / d->stride + 1;
     const int Npad = (d->Cout + 7) / 8 * 8;
-    PE_REQUIRE(ldy >= Npad, PE_E_INVALID,
-               "pe_conv2d_bwd_weight_bf16: dy pitch %d smaller than Cout rounded up to 8", ldy);
-    WgradParams p;
+    PE_REQUIRE(ldy >= Npad, PE_E_INVALID, "%s: dy pitch %d smaller than Cout rounded up to 8", what,
+               ldy);
     wgrad_defaults(p);
     p.x = static_cast<const uint16_t*>(x);
     p.dy = static_cast<const uint16_t*>(dy);
@@ -506,8 +505,8 @@ extern "C" int32_t pe_conv2d_bwd_weight_bf16(const pe_conv_desc* d, const void* 
         // correlation with the pixel beyond it and must be masked off by the caller
         const int P = 64 / d->Cin;
         const int KWc = (d->KW + P - 1) / P;
-        PE_REQUIRE(d->KH * KWc <= kMaxTaps, PE_E_UNSUPPORTED,
-                   "pe_conv2d_bwd_weight_bf16: filter %dx%d not supported", d->KH, d->KW);
+        PE_REQUIRE(d->KH * KWc <= kMaxTaps, PE_E_UNSUPPORTED, "%s: filter %dx%d not supported",
+                   what, d->KH, d->KW);
         p.Cin = 64;
         p.cshift = d->Cin == 8 ? 3 : (d->Cin == 16 ? 4 : 5);
         p.cmask = d->Cin - 1;
@@ -529,8 +528,37 @@ extern "C" int32_t pe_conv2d_bwd_weight_bf16(const pe_conv_desc* d, const void* 
     p.OH = Ho;
     p.OW = Wo;
     p.ldy = ldy;
+    return PE_OK;
+}
+
+extern "C" int32_t pe_conv2d_bwd_weight_bf16(const pe_conv_desc* d, const void* x, const void* dy,
+                                             int32_t ldy, float* dw, void* workspace,
+                                             size_t workspace_bytes, pe_stream_t stream) {
+    WgradParams p;
+    const int32_t rc = conv_wgrad_params(d, x, dy, ldy, dw, p, "pe_conv2d_bwd_weight_bf16");
+    if (rc != PE_OK) return rc;
     return wgrad_launch(p, workspace, workspace_bytes, as_stream(stream),
                         "pe_conv2d_bwd_weight_bf16");
+}
+
+extern "C" size_t pe_wgrad_batched_workspace_bytes(int64_t total_weight_elems) {
+    return wgrad_batch_workspace_bytes(total_weight_elems > 0 ? (long)total_weight_elems : 0);
+}
+
+extern "C" int32_t pe_conv2d_bwd_weight_batched_bf16(const pe_wgrad_job* jobs, int32_t njobs,
+                                                     void* workspace, size_t workspace_bytes,
+                                                     pe_stream_t stream) {
+    const char* what = "pe_conv2d_bwd_weight_batched_bf16";
+    PE_REQUIRE(jobs != nullptr && njobs >= 1 && njobs <= PE_WGRAD_MAX_BATCH, PE_E_INVALID,
+               "%s: 1 to %d jobs per call", what, PE_WGRAD_MAX_BATCH);
+    static_assert(PE_WGRAD_MAX_BATCH == kWgradMaxBatch, "header and kernel disagree");
+    WgradParams ps[kWgradMaxBatch];
+    for (int j = 0; j < njobs; ++j) {
+        const int32_t rc =
+            conv_wgrad_params(&jobs[j].desc, jobs[j].x, jobs[j].dy, jobs[j].ldy, jobs[j].dw, ps[j], what);
+        if (rc != PE_OK) return rc;
+    }
+    return wgrad_launch_batch(ps, njobs, workspace, workspace_bytes, as_stream(stream), what);
 }
 
 extern "C" int32_t pe_deconv4x4s2_bwd_weight_bf16(int32_t B, int32_t H, int32_t W, int32_t Cin,
@@ -540,9 +568,11 @@ extern "C" int32_t pe_deconv4x4s2_bwd_weight_bf16(int32_t B, int32_t H, int32_t 
     PE_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, PE_E_INVALID,
                "pe_deconv4x4s2_bwd_weight_bf16: sizes must be positive");
     PE_REQUIRE(dw_phases != nullptr, PE_E_INVALID, "pe_deconv4x4s2_bwd_weight_bf16: NULL dw");
+    // the four output parities are four weight gradients of the same size: one batched launch
+    WgradParams ps[4];
     for (int py = 0; py < 2; ++py)
         for (int px = 0; px < 2; ++px) {
-            WgradParams p;
+            WgradParams& p = ps[2 * py + px];
             wgrad_defaults(p);
             p.x = static_cast<const uint16_t*>(x);
             p.dy = static_cast<const uint16_t*>(dy);
@@ -568,11 +598,9 @@ extern "C" int32_t pe_deconv4x4s2_bwd_weight_bf16(int32_t B, int32_t H, int32_t 
             p.ooy = py;
             p.oox = px;
             p.ldy = Cout;
-            const int32_t rc = wgrad_launch(p, workspace, workspace_bytes, as_stream(stream),
-                                            "pe_deconv4x4s2_bwd_weight_bf16");
-            if (rc != PE_OK) return rc;
         }
-    return PE_OK;
+    return wgrad_launch_batch(ps, 4, workspace, workspace_bytes, as_stream(stream),
+                              "pe_deconv4x4s2_bwd_weight_bf16");
 }
 
 extern "C" int32_t pe_stem7x7s2_bwd_weight_bf16(int32_t B, int32_t H2, int32_t W2, int32_t Cout,

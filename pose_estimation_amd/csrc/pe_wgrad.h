@@ -17,6 +17,11 @@ constexpr long kWgradTargetBlocks = 512;
 // of 4 the HRNet step loses what it gained (38.6 ms).
 constexpr long kWgradBigTiles = 8;
 constexpr long kWgradMaxBlocks = 2048;   // upper bound the workspace is sized for
+constexpr int kWgradMaxBatch = 8;        // weight gradients per batched launch
+// Workgroups of a batched launch.  Two per CU measured best on the training steps, where the
+// launch runs beside the main chain (ResNet-50 8.49 / 8.41 / 8.44 / 8.55 ms and HRNet-style
+// 34.9 / 33.0 / 33.3 / 33.9 ms for 256 / 512 / 640 / 1024); alone, more is faster.
+constexpr long kWgradBatchBlocks = 512;
 
 struct WgradParams {
     const uint16_t* x;   // forward input, NHWC bf16, Cx channels per pixel
@@ -49,5 +54,11 @@ size_t wgrad_workspace_bytes(long P);
 
 int32_t wgrad_launch(WgradParams& p, void* workspace, size_t workspace_bytes, hipStream_t st,
                      const char* what);
+
+// Up to kWgradMaxBatch weight gradients in one launch plus one fold launch; the workspace
+// (wgrad_batch_workspace_bytes of the weights' total size) is shared out among the jobs.
+int32_t wgrad_launch_batch(WgradParams* ps, int n, void* workspace, size_t workspace_bytes,
+                           hipStream_t st, const char* what);
+size_t wgrad_batch_workspace_bytes(long P_total);
 
 }  // namespace pe

@@ -72,10 +72,11 @@ __device__ __forceinline__ void wg_wait_vmcnt() {
 // flight (counted vmcnt, one raw barrier per step), for launches that put only one or two
 // workgroups on a CU: every pixel split costs a slab of the weight's size, so large weights run
 // with few splits and must hide their own latency.
+// `bid` of `nwg`: this workgroup's index among the workgroups of ONE weight gradient (the whole
+// grid, or one job's share of a batched launch).
 template <bool FLAT, int NS>
-__global__ __launch_bounds__(256, NS == 1 ? 4 : (NS == 2 ? 2 : 1)) void wgrad_kernel(
-    const WgradParams p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+__device__ __forceinline__ void wgrad_body(const WgradParams& p, int bid, const int nwg,
+                                           char* smem) {
     constexpr int STAGE = 2 * WG_TILE;   // dy tile, then x tile
 
     const int tid = threadIdx.x;
@@ -89,9 +90,7 @@ __global__ __launch_bounds__(256, NS == 1 ? 4 : (NS == 2 ? 2 : 1)) void wgrad_ke
     // XCD-aware order: workgroups that share an XCD (ids congruent mod 8) take a contiguous run
     // of (split, tile) pairs, so the tiles of one pixel split, which all read the same dy and x
     // rows, find them in ONE L2 instead of pulling a copy into each of the eight
-    int bid = blockIdx.x;
     {
-        const int nwg = gridDim.x;
         const int qq = nwg >> 3, r8 = nwg & 7;
         const int xcd = bid & 7, loc = bid >> 3;
         bid = (xcd < r8 ? xcd * (qq + 1) : r8 * (qq + 1) + (xcd - r8) * qq) + loc;
@@ -339,6 +338,34 @@ __global__ __launch_bounds__(256, NS == 1 ? 4 : (NS == 2 ? 2 : 1)) void wgrad_ke
     }
 }
 
+template <bool FLAT, int NS>
+__global__ __launch_bounds__(256, NS == 1 ? 4 : (NS == 2 ? 2 : 1)) void wgrad_kernel(
+    const WgradParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    wgrad_body<FLAT, NS>(p, (int)blockIdx.x, (int)gridDim.x, smem);
+}
+
+// Several weight gradients in ONE launch.  At the training batch a single layer's gradient is a
+// few microseconds of work wrapped in some 19 us of launch, fill, drain and fold latency, and
+// it needs many pixel splits (each a slab of the weight's size) just to occupy the chip.  The
+// layers whose gradients are due together share a launch instead: job j owns workgroups
+// [start[j], start[j+1]), every job runs the general (not FLAT) single-stage body, four
+// workgroups per CU, and one more launch folds all the slabs.
+struct WgradBatch {
+    int n;
+    int start[kWgradMaxBatch + 1];
+    WgradParams job[kWgradMaxBatch];
+};
+static_assert(sizeof(WgradBatch) <= 4096, "the batch travels in the kernel arguments");
+
+__global__ __launch_bounds__(256, 4) void wgrad_batched_kernel(const WgradBatch bt) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    int j = 0;
+    for (int i = 1; i < bt.n; ++i) j += (int)blockIdx.x >= bt.start[i] ? 1 : 0;
+    wgrad_body<false, 1>(bt.job[j], (int)blockIdx.x - bt.start[j], bt.start[j + 1] - bt.start[j],
+                         smem);
+}
+
 // dw[e] += sum over slabs of slab[s][e], in an order fixed by (S, SL) alone, so results repeat
 // bit for bit.  A workgroup owns 256/SL groups of four elements; split lane j adds slabs
 // j, j+SL, ... and the SL partial sums are folded in lane order through LDS.  Small weights
@@ -381,23 +408,13 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     }
 }
 
+static int32_t wgrad_check(const WgradParams& p, const char* what);
+
 int32_t wgrad_launch(WgradParams& p, void* workspace, size_t workspace_bytes, hipStream_t st,
                      const char* what) {
-    PE_REQUIRE(p.x && p.dy && p.dw, PE_E_INVALID, "%s: NULL tensor pointer", what);
-    PE_REQUIRE(p.B > 0 && p.Hi > 0 && p.Wi > 0 && p.Ho > 0 && p.Wo > 0 && p.N > 0 && p.Nw > 0 &&
-                   p.Nw <= p.N,
-               PE_E_INVALID, "%s: sizes must be positive", what);
-    PE_REQUIRE(p.N % 8 == 0 && p.Cin % 8 == 0 && p.Cx % 8 == 0 && p.ldy % 8 == 0, PE_E_UNSUPPORTED,
-               "%s: channel counts must be multiples of 8", what);
-    PE_REQUIRE(p.T >= 1 && p.T <= kMaxTaps, PE_E_UNSUPPORTED, "%s: %d taps (max %d)", what, p.T,
-               kMaxTaps);
-    PE_REQUIRE(aligned(p.x, 16) && aligned(p.dy, 16) && aligned(p.dw, 4), PE_E_INVALID,
-               "%s: tensors must be 16-byte aligned", what);
+    const int32_t ok = wgrad_check(p, what);
+    if (ok != PE_OK) return ok;
     const long M = (long)p.B * p.Ho * p.Wo;
-    PE_REQUIRE(M < 0x7fffffffL && (long)p.B * p.OH * p.OW < 0x7fffffffL &&
-                   (long)p.B * p.Hi * p.Wi < 0x7fffffffL &&
-                   (long)p.Ho * p.Wo < (1L << 22) && p.B < (1 << 20),
-               PE_E_UNSUPPORTED, "%s: pixel counts out of range", what);
     const long ktot = (long)p.T * p.Cin;
     const long P = (long)p.Nw * ktot;
     const long tiles = ((p.N + 127) / 128) * ((ktot + 127) / 128);
@@ -474,6 +491,161 @@ int32_t wgrad_launch(WgradParams& p, void* workspace, size_t workspace_bytes, hi
                                                                               P, p.dw);
     }
     return check_launch(what);
+}
+
+struct WgradFoldJob {
+    const float* slab;
+    float* dw;
+    long P;
+    int S;
+};
+struct WgradFoldBatch {
+    int n;
+    int start[kWgradMaxBatch + 1];
+    WgradFoldJob job[kWgradMaxBatch];
+};
+
+// wgrad_reduce_kernel<4> for every job of a batched launch: 64 groups of four elements per
+// workgroup, four split lanes, slabs added in the same fixed order.
+__global__ __launch_bounds__(256) void wgrad_reduce_batched_kernel(const WgradFoldBatch fb) {
+    constexpr int SL = 4, COLS = 64;
+    __shared__ f32x4 part[256];
+    int j = 0;
+    for (int i = 1; i < fb.n; ++i) j += (int)blockIdx.x >= fb.start[i] ? 1 : 0;
+    const float* slab = fb.job[j].slab;
+    float* dw = fb.job[j].dw;
+    const long P = fb.job[j].P;
+    const int S = fb.job[j].S;
+    const int colt = threadIdx.x % COLS;
+    const int sl = threadIdx.x / COLS;
+    const long i = (long)((int)blockIdx.x - fb.start[j]) * COLS + colt;
+    const bool ok = 4 * i < P;
+    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+    if (ok) {
+        const float* src = slab + 4 * i;
+        int s = sl;
+        for (; s + 3 * SL < S; s += 4 * SL) {
+            const f32x4 v0 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src + (long)s * P));
+            const f32x4 v1 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src + (long)(s + SL) * P));
+            const f32x4 v2 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src + (long)(s + 2 * SL) * P));
+            const f32x4 v3 = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src + (long)(s + 3 * SL) * P));
+            a += v0;
+            a += v1;
+            a += v2;
+            a += v3;
+        }
+        for (; s < S; s += SL)
+            a += __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(src + (long)s * P));
+    }
+    part[threadIdx.x] = a;
+    __syncthreads();
+    if (sl != 0) return;
+    for (int q = 1; q < SL; ++q) a += part[q * COLS + colt];
+    if (ok) {
+        f32x4* d = reinterpret_cast<f32x4*>(dw + 4 * i);
+        *d = *d + a;
+    }
+}
+
+static int32_t wgrad_check(const WgradParams& p, const char* what) {
+    PE_REQUIRE(p.x && p.dy && p.dw, PE_E_INVALID, "%s: NULL tensor pointer", what);
+    PE_REQUIRE(p.B > 0 && p.Hi > 0 && p.Wi > 0 && p.Ho > 0 && p.Wo > 0 && p.N > 0 && p.Nw > 0 &&
+                   p.Nw <= p.N,
+               PE_E_INVALID, "%s: sizes must be positive", what);
+    PE_REQUIRE(p.N % 8 == 0 && p.Cin % 8 == 0 && p.Cx % 8 == 0 && p.ldy % 8 == 0, PE_E_UNSUPPORTED,
+               "%s: channel counts must be multiples of 8", what);
+    PE_REQUIRE(p.T >= 1 && p.T <= kMaxTaps, PE_E_UNSUPPORTED, "%s: %d taps (max %d)", what, p.T,
+               kMaxTaps);
+    PE_REQUIRE(aligned(p.x, 16) && aligned(p.dy, 16) && aligned(p.dw, 4), PE_E_INVALID,
+               "%s: tensors must be 16-byte aligned", what);
+    const long M = (long)p.B * p.Ho * p.Wo;
+    PE_REQUIRE(M < 0x7fffffffL && (long)p.B * p.OH * p.OW < 0x7fffffffL &&
+                   (long)p.B * p.Hi * p.Wi < 0x7fffffffL &&
+                   (long)p.Ho * p.Wo < (1L << 22) && p.B < (1 << 20),
+               PE_E_UNSUPPORTED, "%s: pixel counts out of range", what);
+    return PE_OK;
+}
+
+int32_t wgrad_launch_batch(WgradParams* ps, int n, void* workspace, size_t workspace_bytes,
+                           hipStream_t st, const char* what) {
+    PE_REQUIRE(ps != nullptr && n >= 1 && n <= kWgradMaxBatch, PE_E_INVALID,
+               "%s: 1 to %d jobs per call", what, kWgradMaxBatch);
+    if (n == 1) return wgrad_launch(ps[0], workspace, workspace_bytes, st, what);
+    WgradBatch bt;
+    WgradFoldBatch fb;
+    bt.n = n;
+    fb.n = 0;
+    // work of a job = output tiles x pixels; the chip's 4 x 256 workgroup slots are shared out
+    // in proportion, a job's share divided over its tiles gives its pixel splits
+    double work[kWgradMaxBatch], total = 0.0;
+    long tiles[kWgradMaxBatch], Ms[kWgradMaxBatch];
+    for (int j = 0; j < n; ++j) {
+        const int32_t rc = wgrad_check(ps[j], what);
+        if (rc != PE_OK) return rc;
+        const long ktot = (long)ps[j].T * ps[j].Cin;
+        tiles[j] = ((ps[j].N + 127) / 128) * ((ktot + 127) / 128);
+        Ms[j] = (long)ps[j].B * ps[j].Ho * ps[j].Wo;
+        work[j] = (double)tiles[j] * (double)Ms[j];
+        total += work[j];
+    }
+    static const char* tune = getenv("PE_WGRAD_BATCH_BLOCKS");  // tuning aid
+    long budget = tune ? atol(tune) : kWgradBatchBlocks;
+    if (budget < n || budget > kWgradMaxBlocks) budget = kWgradBatchBlocks;
+    size_t used = 0;
+    int blocks = 0, fold_blocks = 0;
+    for (int j = 0; j < n; ++j) {
+        WgradParams& p = ps[j];
+        const long P = (long)p.Nw * p.T * p.Cin;
+        long share = (long)((double)budget * work[j] / total + 0.5);
+        long splits = (share + tiles[j] - 1) / tiles[j];
+        const long max_splits = (Ms[j] + 255) / 256;
+        if (splits > max_splits) splits = max_splits;
+        if (splits < 1) splits = 1;
+        long mps = (Ms[j] + splits - 1) / splits;
+        mps = (mps + WG_BK - 1) / WG_BK * WG_BK;
+        splits = (Ms[j] + mps - 1) / mps;
+        p.m_per_split = mps;
+        p.tiles = (int)tiles[j];
+        p.splits = (int)splits;
+        p.slab_stride = P;
+        p.slab = nullptr;
+        if (splits > 1) {
+            PE_REQUIRE(P % 4 == 0, PE_E_UNSUPPORTED, "%s: weight size not a multiple of 4", what);
+            const size_t need = (size_t)splits * (size_t)P * sizeof(float);
+            PE_REQUIRE(aligned(p.dw, 16), PE_E_INVALID, "%s: dw must be 16-byte aligned", what);
+            PE_REQUIRE(workspace != nullptr && aligned(workspace, 16) &&
+                           used + need <= workspace_bytes,
+                       PE_E_INVALID, "%s: workspace too small (%zu bytes needed so far)", what,
+                       used + need);
+            p.slab = reinterpret_cast<float*>(static_cast<char*>(workspace) + used);
+            used += (need + 255) & ~(size_t)255;
+            WgradFoldJob& f = fb.job[fb.n];
+            f.slab = p.slab;
+            f.dw = p.dw;
+            f.P = P;
+            f.S = (int)splits;
+            fb.start[fb.n] = fold_blocks;
+            fold_blocks += (int)(((P >> 2) + 63) / 64);
+            ++fb.n;
+        }
+        bt.start[j] = blocks;
+        bt.job[j] = p;
+        blocks += (int)(tiles[j] * splits);
+    }
+    bt.start[n] = blocks;
+    fb.start[fb.n] = fold_blocks;
+    const size_t lds1 = 64 * 132 * sizeof(float);
+    pe::launch(wgrad_batched_kernel, (unsigned)blocks, 256, lds1, st, bt);
+    int32_t rc = check_launch(what);
+    if (rc != PE_OK || fb.n == 0) return rc;
+    pe::launch(wgrad_reduce_batched_kernel, (unsigned)fold_blocks, 256, 0, st, fb);
+    return check_launch(what);
+}
+
+size_t wgrad_batch_workspace_bytes(long P_total) {
+    // sum of splits_j * P_j <= 16384 * (budget + tiles) + P_total, each slab rounded up to 256 B
+    return (size_t)(kWgradMaxBlocks + 64) * 16384 * sizeof(float) +
+           2 * (size_t)P_total * sizeof(float) + 256 * (size_t)kWgradMaxBatch;
 }
 
 size_t wgrad_workspace_bytes(long P) {

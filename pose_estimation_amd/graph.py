@@ -456,14 +456,17 @@ class TrainGraph:
             return
         pending, self._pending_wg = self._pending_wg, []
         with self._beside(*[t for (_, x, dz, _) in pending for t in (x, dz)]):
+            # the implicit-GEMM layers of the batch share one launch (and one fold launch)
+            convs = [(x, dz, self._g(L.name + ".weight"), L.k, L.stride, L.pad, cout)
+                     for L, x, dz, cout in pending if L.kind not in ("stem3", "dw")]
+            if convs:
+                pnn.conv2d_bwd_weight_batched(convs)
             for L, x, dz, cout in pending:
                 gw = self._g(L.name + ".weight")
                 if L.kind == "stem3":
                     pnn.stem3x3s2_bwd_weight(x, dz, gw)
                 elif L.kind == "dw":
                     pnn.depthwise3x3_bwd_weight(x, dz, gw, L.stride, L.dilation)
-                else:
-                    pnn.conv2d_bwd_weight(x, dz, gw, L.k, L.stride, L.pad, cout=cout)
                 m = self.masks.get(L.name)
                 if m is not None:
                     pnn.mul_(gw, m)

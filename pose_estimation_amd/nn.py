@@ -8,12 +8,13 @@ architecture can be loaded tensor by tensor.
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import Optional
 
 import numpy as np
 import torch
 
-from ._ffi import ConvDesc, check, lib
+from ._ffi import PE_WGRAD_MAX_BATCH, ConvDesc, WgradJob, check, lib
 from .ops import _need_gpu, _ptr, _stream, on_device
 
 BF16 = torch.bfloat16
@@ -727,6 +728,55 @@ def wgrad_workspace(weight_elems: int, device) -> torch.Tensor:
     return ws
 
 
+def wgrad_batched_workspace(total_weight_elems: int, device) -> torch.Tensor:
+    """Scratch for a batched weight-gradient launch (the same cached buffer as the single
+    launches use, grown on demand)."""
+    need = lib().pe_wgrad_batched_workspace_bytes(int(total_weight_elems))
+    key = str(device)
+    ws = _wgrad_ws.get(key)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(need, dtype=torch.uint8, device=device)
+        _wgrad_ws[key] = ws
+    return ws
+
+
+def _wgrad_elems(Cin: int, cout: int, k: int) -> int:
+    return cout * k * ((k + 64 // Cin - 1) // (64 // Cin)) * 64 if Cin in (8, 16, 32) \
+        else cout * k * k * Cin
+
+
+def conv2d_bwd_weight_batched(jobs) -> None:
+    """jobs: sequence of (x, dy, dw, k, stride, pad, cout or None), each what one
+    conv2d_bwd_weight call takes.  The weight gradients of up to PE_WGRAD_MAX_BATCH layers go
+    out as ONE launch plus one fold launch (longer lists are cut into such batches)."""
+    jobs = list(jobs)
+    if os.environ.get("PE_WGRAD_BATCHED", "1") == "0":      # comparison switch: one launch each
+        for x, dy, dw, k, stride, pad, cout in jobs:
+            conv2d_bwd_weight(x, dy, dw, k, stride, pad, cout)
+        return
+    for at in range(0, len(jobs), PE_WGRAD_MAX_BATCH):
+        part = jobs[at:at + PE_WGRAD_MAX_BATCH]
+        arr = (WgradJob * len(part))()
+        total = 0
+        for j, (x, dy, dw, k, stride, pad, cout) in enumerate(part):
+            _check_act(x)
+            _check_act(dy, "dy")
+            B, H, W, Cin = x.shape
+            ldy = dy.shape[3]
+            cout = ldy if cout is None else cout
+            if dw.dtype != torch.float32 or dw.numel() != _wgrad_elems(Cin, cout, k) \
+                    or not dw.is_contiguous():
+                raise ValueError("dw must be contiguous float32 in the forward weight's packed layout")
+            arr[j].desc = ConvDesc(B, H, W, Cin, cout, k, k, stride, pad, 0, 0)
+            arr[j].x, arr[j].dy, arr[j].dw, arr[j].ldy = x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ldy
+            total += dw.numel()
+        x0 = part[0][0]
+        with on_device(x0):
+            ws = wgrad_batched_workspace(total, x0.device)
+            check(lib().pe_conv2d_bwd_weight_batched_bf16(ctypes.byref(arr), len(part), ws.data_ptr(),
+                                                          ws.numel(), _stream(x0)))
+
+
 def conv2d_bwd_weight(x: torch.Tensor, dy: torch.Tensor, dw: torch.Tensor, k: int, stride: int,
                       pad: int, cout: Optional[int] = None) -> None:
     """dw (float32 [Cout,k,k,Cin], pre-zeroed) += weight gradient.  dy may be zero-padded to more
@@ -736,9 +786,7 @@ def conv2d_bwd_weight(x: torch.Tensor, dy: torch.Tensor, dw: torch.Tensor, k: in
     B, H, W, Cin = x.shape
     ldy = dy.shape[3]
     cout = ldy if cout is None else cout
-    elems = cout * k * ((k + 64 // Cin - 1) // (64 // Cin)) * 64 if Cin in (8, 16, 32) \
-        else cout * k * k * Cin
-    if dw.dtype != torch.float32 or dw.numel() != elems or not dw.is_contiguous():
+    if dw.dtype != torch.float32 or dw.numel() != _wgrad_elems(Cin, cout, k) or not dw.is_contiguous():
         raise ValueError("dw must be contiguous float32 in the forward weight's packed layout")
     d = ConvDesc(B, H, W, Cin, cout, k, k, stride, pad, 0, 0)
     with on_device(x):
@@ -756,7 +804,7 @@ def deconv4x4s2_bwd_weight(x: torch.Tensor, dy: torch.Tensor, dw: torch.Tensor) 
     if dw.dtype != torch.float32 or dw.numel() != 16 * Cout * Cin:
         raise ValueError("dw must be float32 [4,Cout,4,Cin]")
     with on_device(x):
-        ws = wgrad_workspace(dw.numel() // 4, x.device)
+        ws = wgrad_batched_workspace(dw.numel(), x.device)   # four phases, one batched launch
         check(lib().pe_deconv4x4s2_bwd_weight_bf16(B, H, W, Cin, Cout, x.data_ptr(), dy.data_ptr(),
                                                    dw.data_ptr(), ws.data_ptr(), ws.numel(),
                                                    _stream(x)))

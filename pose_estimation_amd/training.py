@@ -61,6 +61,7 @@ class TrainablePoseResNet(PoseResNet):
         self._wt_pending = False
         self._recorded: Dict[tuple, "replay.RecordedPass"] = {}
         self._keep: list = []
+        self._pending_wg: list = []
         # backward-data GEMMs mask their result and reduce it for the batch norm below them
         # (PE_FUSE_BN_BWD=0: the separate reduction pass, for comparison)
         self.fuse_bn_bwd = os.environ.get("PE_FUSE_BN_BWD", "1") != "0"
@@ -207,9 +208,10 @@ class TrainablePoseResNet(PoseResNet):
         z3, out = self._conv_bn(b.c3, a2, residual=idn, relu=True)
         return dict(x=x, z1=z1, a1=a1, z2=z2, a2=a2, z3=z3, zd=zd, out=out)
 
-    def block_backward(self, b, s: dict, dout: torch.Tensor) -> torch.Tensor:
+    def block_backward(self, b, s: dict, dout: torch.Tensor, flush: bool = True) -> torch.Tensor:
         """Backward of block_forward: accumulates the block's parameter gradients into the
-        gradient arena and returns the gradient with respect to the block input."""
+        gradient arena and returns the gradient with respect to the block input.  flush=False
+        leaves the block's weight gradients queued for a batched launch with later layers'."""
         self._join_transposes()
         x = s["x"]
         hw_in = tuple(x.shape[1:3])
@@ -217,34 +219,27 @@ class TrainablePoseResNet(PoseResNet):
         dz3, g3 = self._bn_bwd(b.c3, dout, s["out"], s["z3"], want_masked=True)
         if b.down:
             dzd, _ = self._bn_bwd(b.down, g3, None, s["zd"])
-            with self._beside(s["a2"], dz3, x, dzd):
-                pnn.conv2d_bwd_weight(s["a2"], dz3, self._g(b.c3.name + ".weight"), 1, 1, 0)
-                pnn.conv2d_bwd_weight(x, dzd, self._g(b.down.name + ".weight"), 1, b.down.stride, 0)
-                # the arena holds `down` after conv3, so it is finished before conv3 is marked
-                self._done(b.down)
-                self._done(b.c3)
+            # the arena holds `down` after conv3, so it is finished before conv3 is marked
+            self._weight_grad(b.down, x, dzd, 1, b.down.stride, 0)
+            self._weight_grad(b.c3, s["a2"], dz3, 1, 1, 0)
             res = pnn.conv2d_bwd_data(dzd, self.wt[b.down.name], hw_in, 1, b.down.stride, 0)
         else:
-            with self._beside(s["a2"], dz3):
-                pnn.conv2d_bwd_weight(s["a2"], dz3, self._g(b.c3.name + ".weight"), 1, 1, 0)
-                self._done(b.c3)
+            self._weight_grad(b.c3, s["a2"], dz3, 1, 1, 0)
             res = g3
         if self.fuse_bn_bwd:
             dz2 = self._bwd_data_bn(b.c2, s["z2"], dz3, self.wt[b.c3.name], 1, 1, 0)
         else:
             da2 = pnn.conv2d_bwd_data(dz3, self.wt[b.c3.name], tuple(s["a2"].shape[1:3]), 1, 1, 0)
             dz2, _ = self._bn_bwd(b.c2, da2, s["a2"], s["z2"], rebuild=True)
-        with self._beside(s["a1"], dz2):
-            pnn.conv2d_bwd_weight(s["a1"], dz2, self._g(b.c2.name + ".weight"), 3, b.c2.stride, 1)
-            self._done(b.c2)
+        self._weight_grad(b.c2, s["a1"], dz2, 3, b.c2.stride, 1)
         if self.fuse_bn_bwd and hw_mid[0] % b.c2.stride == 0 and hw_mid[1] % b.c2.stride == 0:
             dz1 = self._bwd_data_bn(b.c1, s["z1"], dz2, self.wt[b.c2.name], 3, b.c2.stride, 1)
         else:
             da1 = pnn.conv2d_bwd_data(dz2, self.wt[b.c2.name], hw_mid, 3, b.c2.stride, 1)
             dz1, _ = self._bn_bwd(b.c1, da1, s["a1"], s["z1"], rebuild=True)
-        with self._beside(x, dz1):
-            pnn.conv2d_bwd_weight(x, dz1, self._g(b.c1.name + ".weight"), 1, 1, 0)
-            self._done(b.c1)
+        self._weight_grad(b.c1, x, dz1, 1, 1, 0)
+        if flush:
+            self._flush_weight_grads()
         return pnn.conv2d_bwd_data(dz1, self.wt[b.c1.name], hw_in, 1, 1, 0, residual=res)
 
     def deconv_forward(self, d, x: torch.Tensor) -> dict:
@@ -255,6 +250,7 @@ class TrainablePoseResNet(PoseResNet):
     def deconv_backward(self, d, s: dict, da: torch.Tensor) -> torch.Tensor:
         self._join_transposes()
         dz, _ = self._bn_bwd(d, da, s["a"], s["z"], rebuild=True)
+        self._flush_weight_grads()
         with self._beside(s["x"], dz):
             pnn.deconv4x4s2_bwd_weight(s["x"], dz, self._g(d.name + ".weight"))
             self._done(d)
@@ -325,6 +321,30 @@ class TrainablePoseResNet(PoseResNet):
                                         self._g(below.name + ".bn.beta"), ws,
                                         frozen=self.freeze_bn, sync=self.bn_sync)
 
+    WGRAD_BATCH = 8   # conv weight gradients per batched launch (and per fork to the side stream)
+
+    def _weight_grad(self, c: ConvSpec, x: torch.Tensor, dz: torch.Tensor, k: int, stride: int,
+                     pad: int, cout: Optional[int] = None) -> None:
+        """Queues a conv layer's weight gradient.  At batch 64 one layer's gradient is a few
+        microseconds of work inside some 19 us of launch, fill, drain and fold latency, so the
+        layers whose gradients are due together go out as one batched launch on the side
+        stream (nothing reads them before the optimizer).  Layers are marked done, in the order
+        they were queued, once that launch is enqueued."""
+        self._pending_wg.append((c, x, dz, k, stride, pad, cout))
+        if len(self._pending_wg) >= self.WGRAD_BATCH:
+            self._flush_weight_grads()
+
+    def _flush_weight_grads(self) -> None:
+        if not self._pending_wg:
+            return
+        pending, self._pending_wg = self._pending_wg, []
+        with self._beside(*[t for (_, x, dz, *_r) in pending for t in (x, dz)]):
+            pnn.conv2d_bwd_weight_batched(
+                [(x, dz, self._g(c.name + ".weight"), k, stride, pad, cout)
+                 for (c, x, dz, k, stride, pad, cout) in pending])
+            for c, *_r in pending:
+                self._done(c)
+
     def _done(self, c: ConvSpec) -> None:
         if self.bucketer is not None:
             self.bucketer.layer_done(self.offsets[c.name + ".weight"][0])
@@ -355,10 +375,7 @@ class TrainablePoseResNet(PoseResNet):
         self.grads.zero_()
         # final 1x1 conv + bias
         dyp = pnn.final_grad_prepare(grad_hm, FINAL_KPAD, self._g(final.name + ".bias"))
-        with self._beside(sv["feat"], dyp):
-            pnn.conv2d_bwd_weight(sv["feat"], dyp, self._g(final.name + ".weight"), 1, 1, 0,
-                                  cout=final.cout)
-            self._done(final)
+        self._weight_grad(final, sv["feat"], dyp, 1, 1, 0, cout=final.cout)
         H, W = sv["feat"].shape[1:3]
         # deconv head.  With the fused batch-norm backward every backward-data GEMM of the chain
         # hands the layer below its dz directly (mask and sums in the GEMM epilogue).
@@ -372,6 +389,7 @@ class TrainablePoseResNet(PoseResNet):
             d, s = deconvs[i], sv["deconvs"][i]
             if dz is None:
                 dz, _ = self._bn_bwd(d, dx, s["a"], s["z"], rebuild=True)
+            self._flush_weight_grads()      # layers are marked done in arena order
             with self._beside(s["x"], dz):
                 pnn.deconv4x4s2_bwd_weight(s["x"], dz, self._g(d.name + ".weight"))
                 self._done(d)
@@ -383,11 +401,12 @@ class TrainablePoseResNet(PoseResNet):
                 dz = None
         # bottleneck blocks
         for b, s in zip(reversed(blocks), reversed(sv["blocks"])):
-            dx = self.block_backward(b, s, dx)
+            dx = self.block_backward(b, s, dx, flush=False)
         # stem
         da0 = pnn.maxpool3x3s2_bwd(sv["pool_idx"], dx)
         dz0, _ = self._bn_bwd(stem, da0, sv["a0"], sv["z0"], rebuild=True)
         gw = self._g(stem.name + ".weight")
+        self._flush_weight_grads()
         with self._beside(sv["xs"], dz0):
             pnn.stem7x7s2_bwd_weight(sv["xs"], dz0, gw)
             pnn.mul_(gw, self.stem_mask)

@@ -116,6 +116,44 @@ def test_conv_bwd_weight(case):
     close(dw.cpu(), 2 * ref, 1e-4)
 
 
+def test_conv_bwd_weight_batched_equals_the_single_calls():
+    """Every case of the list above (1x1 / 3x3 / strided / narrow inputs) as jobs of batched
+    launches: integer operands make every partial sum exact, so the batched result must equal
+    torch's weight gradient bit for bit whatever the order of the pixel splits; with random
+    operands it must match the single calls to float32 rounding.  A second batched call adds on
+    top, and a batch of more than PE_WGRAD_MAX_BATCH jobs is cut into several launches."""
+    g = torch.Generator().manual_seed(77)
+    jobs, refs, singles = [], [], []
+    for integer in (True, False):
+        for case in BWD_CASES + BWD_CASES[:3]:
+            B, H, W, Cin, Cout, k, s, p = case
+            Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+            if integer:
+                x, dy = ints((B, H, W, Cin), g, -2, 2), ints((B, Ho, Wo, Cout), g, -1, 1)
+            else:
+                x, dy = rnd((B, H, W, Cin), g), rnd((B, Ho, Wo, Cout), g)
+            ref = torch.nn.grad.conv2d_weight(nchw(x), (Cout, Cin, k, k), nchw(dy), stride=s, padding=p)
+            refs.append((integer, ref.permute(0, 2, 3, 1).contiguous()))
+            xg, dyg = x.to(BF16).cuda(), dy.to(BF16).cuda()
+            jobs.append((xg, dyg, torch.zeros(Cout, k, k, Cin, device="cuda"), k, s, p, None))
+            one = torch.zeros(Cout, k, k, Cin, device="cuda")
+            pnn.conv2d_bwd_weight(xg, dyg, one, k, s, p)
+            singles.append(one)
+    assert len(jobs) > pnn.PE_WGRAD_MAX_BATCH
+    pnn.conv2d_bwd_weight_batched(jobs)
+    for (integer, ref), job, one in zip(refs, jobs, singles):
+        if integer:
+            assert torch.equal(job[2].cpu(), ref)
+        else:
+            close(job[2].cpu(), ref, 1e-4)
+            close(job[2].cpu(), one.cpu(), 1e-5)
+    pnn.conv2d_bwd_weight_batched(jobs[:3])
+    for (integer, ref), job in list(zip(refs, jobs))[:3]:
+        assert torch.equal(job[2].cpu(), 2 * ref)
+    with pytest.raises(ValueError, match="packed layout"):
+        pnn.conv2d_bwd_weight_batched([jobs[0][:2] + (torch.zeros(3, device="cuda"),) + jobs[0][3:]])
+
+
 def test_bwd_weight_large_reduction_and_padded_dy():
     """Final layer shape: 256 -> 17 channels with dy zero-padded to 64, M = B*64*48 pixels."""
     g = torch.Generator().manual_seed(31)
