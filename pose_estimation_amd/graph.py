@@ -182,6 +182,7 @@ class TrainGraph:
         # launch instead of before it (ResNet-50 step 9.25 vs 8.93 ms, HRNet 37.8 vs 37.2 ms,
         # MobileNetV2 16.13 vs 16.17 ms), so the separate finalize launch stays the default.
         self.bn_sync = pnn.bn_sync(dev) if os.environ.get("PE_BN_FUSED", "0") == "1" else None
+        self._syncs: Dict[int, torch.Tensor] = {}
         # ... when the GEMM's reduction is long enough to carry the heavier epilogue: with a
         # short one (a pointwise conv from 64 channels) the separate pass measured faster
         self.fuse_min_k = int(os.environ.get("PE_FUSE_MIN_K", "256"))
@@ -294,6 +295,17 @@ class TrainGraph:
         self.work.copy_(self.master)
         self.refresh_transposes()
 
+    def _sync(self) -> Optional[torch.Tensor]:
+        """The one-launch batch norm's hand-off buffer of the current stream (launches that share
+        a buffer must be issued from one stream), or None when that variant is off."""
+        if self.bn_sync is None:
+            return None
+        key = torch.cuda.current_stream(self.device).cuda_stream
+        buf = self._syncs.get(key)
+        if buf is None:
+            buf = self._syncs[key] = pnn.bn_sync(self.device)
+        return buf
+
     def _workspace_for(self, M: int, C: int) -> torch.Tensor:
         """Scratch for batch-norm partial sums: one buffer per stream, since a producer's rows
         must survive until the finalize behind it on the same stream has read them and branches
@@ -348,7 +360,7 @@ class TrainGraph:
                 out = Var(pnn.bn_stats_apply(z, gamma, beta, BN_EPS, self.bn_momentum,
                                              self.bn_mean[L.name], self.bn_var[L.name],
                                              self._workspace_for(M, L.cout),
-                                             self.bn_rows[L.name], self.bn_sync, res_t, act))
+                                             self.bn_rows[L.name], self._sync(), res_t, act))
             else:
                 _, _, scale, shift = pnn.bn_stats(z, gamma, beta, BN_EPS, self.bn_momentum,
                                                   self.bn_mean[L.name], self.bn_var[L.name],
@@ -376,7 +388,7 @@ class TrainGraph:
             out = Var(pnn.bn_finalize_apply(ws, rows, z, gamma, beta, BN_EPS,
                                             self.bn_momentum, self.bn_mean[L.name],
                                             self.bn_var[L.name], self.bn_rows[L.name],
-                                            self.bn_sync, res_t, act))
+                                            self._sync(), res_t, act))
         else:
             _, _, scale, shift = pnn.bn_finalize(
                 ws, rows, M, L.cout, gamma, beta, BN_EPS, self.bn_momentum,
@@ -495,7 +507,7 @@ class TrainGraph:
             x.dz = pnn.bn_bwd_from_partials(
                 g, zb, rows, self.view(self.master, Lb.name + ".bn.gamma"), buf[0], buf[1],
                 self._g(Lb.name + ".bn.gamma"), self._g(Lb.name + ".bn.beta"), ws,
-                frozen=self.freeze_bn, sync=self.bn_sync)
+                frozen=self.freeze_bn, sync=self._sync())
             x.grad = g
             return
         fused = x.grad is not None and not (L.k == 1 and L.stride == 2)
@@ -557,7 +569,7 @@ class TrainGraph:
                                    self._workspace_for(z.numel() // L.cout, L.cout), masked,
                                    relu=act or 1, act_scale=buf[2] if rebuild else None,
                                    act_shift=buf[3] if rebuild else None, frozen=self.freeze_bn,
-                                   sync=self.bn_sync)
+                                   sync=self._sync())
                 if residual is not None:
                     self._acc(residual, g if masked else out.grad)
                 self._weight_grad(L, x.t, dz)

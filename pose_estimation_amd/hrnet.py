@@ -375,7 +375,7 @@ class TrainablePoseHRNet(TrainGraph):
         # main stream and freed there; the side streams start every module behind the main
         # stream, so their next allocation is ordered after those readers.  The one-launch batch
         # norm's hand-off buffer belongs to one stream, so not with it.
-        self.multi_stream = (self.branch_streams and self.bn_sync is None
+        self.multi_stream = (self.branch_streams
                              and os.environ.get("PE_HRNET_TRAIN_STREAMS", "1") != "0")
 
     def _u(self, u: Unit, x, residual=None, relu=None):
