@@ -552,6 +552,17 @@ int32_t pe_conv2d_bwd_data_bnmask_bf16(const pe_conv_desc* d, const void* dy, co
                                        const float* act_shift, int32_t relu, void* g,
                                        void* bn_workspace, size_t workspace_bytes,
                                        int32_t* rows_out, pe_stream_t stream);
+/* The same fusion for a RESIDUAL layer below: a = relu(bn(z) + identity) cannot be rebuilt from
+ * z, so the mask is read from the stored activation `act` [B,H,W,Cin] bf16 (ReLU only), and the
+ * value that is masked is the GEMM's result plus `residual` (NULL: none), i.e. the whole gradient
+ * of `act` when this conv is the last of its consumers to be differentiated:
+ *   g = act > 0 ? bf16(conv_bwd_data(dy) + residual) : 0,  partial rows {sum g, sum g*z}.
+ * Replaces pe_conv2d_bwd_data_bf16(residual) + the reduction pass of pe_bn_bwd_bf16(a = act):
+ * a reduction launch and three tensor reads less per residual block; g is bit-identical. */
+int32_t pe_conv2d_bwd_data_resmask_bf16(const pe_conv_desc* d, const void* dy, const void* w_t,
+                                        const void* residual, const void* act, const void* z,
+                                        void* g, void* bn_workspace, size_t workspace_bytes,
+                                        int32_t* rows_out, pe_stream_t stream);
 int32_t pe_deconv4x4s2_bwd_data_bnmask_bf16(int32_t B, int32_t H, int32_t W, int32_t Cin,
                                             int32_t Cout, const void* dy, const void* w_t,
                                             const void* z, const float* act_scale,

@@ -220,6 +220,9 @@ SIGNATURES = {
     "pe_conv2d_bwd_data_bnmask_bf16": (
         c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32, c_void_p,
                   c_void_p, c_size_t, c_void_p, c_void_p]),
+    "pe_conv2d_bwd_data_resmask_bf16": (
+        c_int32, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                  c_size_t, c_void_p, c_void_p]),
     "pe_deconv4x4s2_bwd_data_bnmask_bf16": (
         c_int32, [c_int32] * 5 + [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int32,
                                   c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),

@@ -263,6 +263,7 @@ struct MaskReq {
     const float* act_scale;
     const float* act_shift;
     int32_t relu;            // 1: ReLU, 2: ReLU6
+    const void* act;         // residual layers: the stored activation gives the mask (ReLU)
     void* workspace;
     size_t bytes;
     int32_t* rows_out;
@@ -270,12 +271,17 @@ struct MaskReq {
 
 static int32_t attach_mask(IgemmParams& p, const MaskReq* mr, const char* what) {
     if (mr == nullptr) return PE_OK;
-    PE_REQUIRE(mr->z && mr->act_scale && mr->act_shift && mr->workspace && mr->rows_out,
+    PE_REQUIRE(mr->z && mr->workspace && mr->rows_out && (mr->act || (mr->act_scale && mr->act_shift)),
                PE_E_INVALID, "%s: NULL mask operand", what);
-    PE_REQUIRE(mr->relu == 1 || mr->relu == 2, PE_E_INVALID, "%s: relu must be 1 or 2", what);
+    PE_REQUIRE(mr->relu == 1 || (mr->relu == 2 && !mr->act), PE_E_INVALID,
+               "%s: relu must be 1 or 2 (1 with a stored activation)", what);
     PE_REQUIRE(aligned(mr->workspace, 16) && p.N % 8 == 0, PE_E_INVALID,
                "%s: the fused mask needs an aligned workspace and Cin %% 8 == 0", what);
-    PE_REQUIRE(p.res == nullptr, PE_E_UNSUPPORTED, "%s: the fused mask takes no residual", what);
+    PE_REQUIRE(p.res == nullptr || mr->act != nullptr, PE_E_UNSUPPORTED,
+               "%s: a residual needs the mask from the stored activation", what);
+    PE_REQUIRE(aligned(mr->z, 16) && aligned(mr->act, 16), PE_E_INVALID,
+               "%s: z and the activation must be 16-byte aligned", what);
+    p.mask_a = static_cast<const uint16_t*>(mr->act);
     p.mask_z = static_cast<const uint16_t*>(mr->z);
     p.mask_sc = mr->act_scale;
     p.mask_sh = mr->act_shift;
@@ -409,8 +415,18 @@ extern "C" int32_t pe_conv2d_bwd_data_bnmask_bf16(const pe_conv_desc* d, const v
                                                   int32_t relu, void* g, void* bn_workspace,
                                                   size_t workspace_bytes, int32_t* rows_out,
                                                   pe_stream_t stream) {
-    const MaskReq mr{z, act_scale, act_shift, relu, bn_workspace, workspace_bytes, rows_out};
+    const MaskReq mr{z, act_scale, act_shift, relu, nullptr, bn_workspace, workspace_bytes, rows_out};
     return conv2d_bwd_data_impl(d, dy, w_t, nullptr, g, &mr, stream);
+}
+
+extern "C" int32_t pe_conv2d_bwd_data_resmask_bf16(const pe_conv_desc* d, const void* dy,
+                                                   const void* w_t, const void* residual,
+                                                   const void* act, const void* z, void* g,
+                                                   void* bn_workspace, size_t workspace_bytes,
+                                                   int32_t* rows_out, pe_stream_t stream) {
+    PE_REQUIRE(act != nullptr, PE_E_INVALID, "pe_conv2d_bwd_data_resmask_bf16: NULL activation");
+    const MaskReq mr{z, nullptr, nullptr, 1, act, bn_workspace, workspace_bytes, rows_out};
+    return conv2d_bwd_data_impl(d, dy, w_t, residual, g, &mr, stream);
 }
 
 static int32_t deconv_bwd_data_impl(int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout,
@@ -468,7 +484,7 @@ extern "C" int32_t pe_deconv4x4s2_bwd_data_bnmask_bf16(int32_t B, int32_t H, int
                                                        void* g, void* bn_workspace,
                                                        size_t workspace_bytes, int32_t* rows_out,
                                                        pe_stream_t stream) {
-    const MaskReq mr{z, act_scale, act_shift, relu, bn_workspace, workspace_bytes, rows_out};
+    const MaskReq mr{z, act_scale, act_shift, relu, nullptr, bn_workspace, workspace_bytes, rows_out};
     return deconv_bwd_data_impl(B, H, W, Cin, Cout, dy, w_t, g, &mr, stream);
 }
 

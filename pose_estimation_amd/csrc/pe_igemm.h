@@ -60,6 +60,10 @@ struct IgemmParams {
     const float* mask_sc;
     const float* mask_sh;
     float mask_hi;            // +inf: ReLU, 6: ReLU6
+    // Residual layers: a = relu(bn(z) + identity) cannot be rebuilt from z, so the mask is read
+    // from the stored activation (mask_a, same layout as the output; mask_sc / mask_sh unused),
+    // and `res` may be set: the masked value is the GEMM's result plus the residual.
+    const uint16_t* mask_a;
     int32_t tap_info[kMaxTaps];  // dy | dx << 8 | slot << 16, packed by igemm_launch for the kernel
     // Optional phases (gridDim.y): phase i uses taps [ph_t0[i], ph_t0[i] + ph_T[i]), the row grid
     // ph_Ho[i] x ph_Wo[i], output offset (ph_ooy[i], ph_oox[i]) and weights w + ph_woff[i].

@@ -72,7 +72,7 @@ __device__ __forceinline__ void wait_vmcnt() {
 // lies inside the image"), and a K step adds a wave-uniform byte offset.  Needs single-pixel K
 // runs, Cin a multiple of 64 and at most 32 taps per phase (igemm_launch checks).
 template <int BM, int BN, int WM, int PIPE, bool PF, int MINB, bool MASK = false, int WN = 2,
-          bool FAST = false>
+          bool FAST = false, bool RES = false>
 __global__ __launch_bounds__(WM * WN * 64, MINB)
 __attribute__((amdgpu_waves_per_eu(MINB * WM * WN / 4, MINB * WM * WN / 4))) void igemm_kernel(const IgemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -468,6 +468,32 @@ __attribute__((amdgpu_waves_per_eu(MINB * WM * WN / 4, MINB * WM * WN / 4))) voi
                     if constexpr (MASK) {
                         const uint4 zv = rres[pass];
                         const uint32_t zu[4] = {zv.x, zv.y, zv.z, zv.w};
+                        if constexpr (RES) {   // mask from the stored activation (+ residual)
+                            const uint4 av = *reinterpret_cast<const uint4*>(p.mask_a + opix * p.ldc + n);
+                            const uint32_t au[4] = {av.x, av.y, av.z, av.w};
+                            if (p.res) {
+                                const uint4 rv =
+                                    *reinterpret_cast<const uint4*>(p.res + opix * p.ldc + n);
+                                const uint32_t ru[4] = {rv.x, rv.y, rv.z, rv.w};
+#pragma unroll
+                                for (int i = 0; i < 4; ++i) {
+                                    v[2 * i] += bf16_bits_to_float(ru[i] & 0xffffu);
+                                    v[2 * i + 1] += bf16_bits_to_float(ru[i] >> 16);
+                                }
+                            }
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) {
+                                const uint32_t zb = (i & 1) ? (zu[i >> 1] >> 16) : (zu[i >> 1] & 0xffffu);
+                                const uint32_t ab = (i & 1) ? (au[i >> 1] >> 16) : (au[i >> 1] & 0xffffu);
+                                const float zf = bf16_bits_to_float(zb);
+                                const float g = bf16_bits_to_float(ab) > 0.0f
+                                                    ? bf16_bits_to_float(float_to_bf16_bits(v[i]))
+                                                    : 0.0f;
+                                v[i] = g;
+                                ms1[i] += g;
+                                ms2[i] += g * zf;
+                            }
+                        } else {
                         // scale and shift of this thread's 8 channels (n < N and N % 8 == 0 here);
                         // re-read per pass from the cache rather than held across the epilogue
                         const f32x4 c0 = *reinterpret_cast<const f32x4*>(p.mask_sc + n);
@@ -490,6 +516,7 @@ __attribute__((amdgpu_waves_per_eu(MINB * WM * WN / 4, MINB * WM * WN / 4))) voi
                             v[i] = g;
                             ms1[i] += g;
                             ms2[i] += g * zf;
+                        }
                         }
                     } else if (p.res) {
                         const uint4 rv = rres[pass];
@@ -616,7 +643,7 @@ static constexpr size_t lds_bytes() {
 }
 
 template <int BM, int BN, int WM, int PIPE, bool PF, int MINB, bool MASK = false, int WN = 2,
-          bool FAST = false>
+          bool FAST = false, bool RES = false>
 static int32_t launch_cfg(IgemmParams& p, long maxM, hipStream_t st, const char* what) {
     const long ntm = (maxM + BM - 1) / BM;
     p.stat_ntm = (int)ntm;
@@ -633,11 +660,11 @@ static int32_t launch_cfg(IgemmParams& p, long maxM, hipStream_t st, const char*
     if constexpr (lds > 64 * 1024) {
         static const hipError_t once = hipFuncSetAttribute(
             reinterpret_cast<const void*>(
-                &igemm_kernel<BM, BN, WM, PIPE, PF, MINB, MASK, WN, FAST>),
+                &igemm_kernel<BM, BN, WM, PIPE, PF, MINB, MASK, WN, FAST, RES>),
             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)once;
     }
-    pe::launch(igemm_kernel<BM, BN, WM, PIPE, PF, MINB, MASK, WN, FAST>, grid, WM * WN * 64, lds, st, p);
+    pe::launch(igemm_kernel<BM, BN, WM, PIPE, PF, MINB, MASK, WN, FAST, RES>, grid, WM * WN * 64, lds, st, p);
     return check_launch(what);
 }
 
@@ -683,7 +710,9 @@ int32_t igemm_launch(const IgemmParams& pin, hipStream_t st, const char* what) {
         if (M > maxM) maxM = M;
     }
     if (p.stat_partial) {
-        PE_REQUIRE(!p.scale && !p.shift && !p.res && !p.relu && p.out_mode == 0 &&
+        // (a residual only together with the mask from a stored activation, which adds it
+        // before masking)
+        PE_REQUIRE(!p.scale && !p.shift && (!p.res || p.mask_a) && !p.relu && p.out_mode == 0 &&
                        (p.N & 7) == 0 && (p.ldc & 7) == 0,
                    PE_E_UNSUPPORTED,
                    "%s: fused statistics need a plain bf16 NHWC output (no scale, shift, residual "
@@ -693,9 +722,9 @@ int32_t igemm_launch(const IgemmParams& pin, hipStream_t st, const char* what) {
                        "%s: fused statistics need equally sized phases", what);
     }
     if (p.mask_z) {
-        PE_REQUIRE(p.stat_partial && p.mask_sc && p.mask_sh, PE_E_INVALID,
-                   "%s: the fused activation mask needs scale, shift and a statistics workspace",
-                   what);
+        PE_REQUIRE(p.stat_partial && (p.mask_a || (p.mask_sc && p.mask_sh)), PE_E_INVALID,
+                   "%s: the fused activation mask needs scale and shift (or the stored "
+                   "activation) and a statistics workspace", what);
         PE_REQUIRE(aligned(p.mask_z, 16) && aligned(p.mask_sc, 16) && aligned(p.mask_sh, 16),
                    PE_E_INVALID, "%s: z, scale and shift must be 16-byte aligned", what);
     }
@@ -764,7 +793,7 @@ int32_t igemm_launch(const IgemmParams& pin, hipStream_t st, const char* what) {
     PE_CFG_RING(128, 128, 2, 2, 2, 2)
     PE_CFG_RING(64, 64, 2, 2, 3, 2)
 #undef PE_CFG_RING
-    if (!force && ring3) {
+    if (!force && ring3 && !p.mask_a) {
         if (p.mask_z) return launch_cfg<64, 64, 2, 3, false, 2, true, 2, true>(p, maxM, st, what);
         return launch_cfg<64, 64, 2, 3, false, 2, false, 2, true>(p, maxM, st, what);
     }
@@ -783,6 +812,10 @@ int32_t igemm_launch(const IgemmParams& pin, hipStream_t st, const char* what) {
 #define PE_CFG_MASK(BM_, BN_, WM_, DB_, PF_, MINB_)                                   \
     if (p.mask_z && bm == BM_ && bn == BN_ && wm == WM_ && db == (DB_ ? 1 : 0) &&     \
         pf == (PF_ ? 1 : 0) && minb == MINB_) {                                        \
+        if (p.mask_a && fast)                                                          \
+            return launch_cfg<BM_, BN_, WM_, DB_, PF_, MINB_, true, 2, true, true>(p, maxM, st, what); \
+        if (p.mask_a)                                                                  \
+            return launch_cfg<BM_, BN_, WM_, DB_, PF_, MINB_, true, 2, false, true>(p, maxM, st, what); \
         if (fast)                                                                      \
             return launch_cfg<BM_, BN_, WM_, DB_, PF_, MINB_, true, 2, true>(p, maxM, st, what); \
         return launch_cfg<BM_, BN_, WM_, DB_, PF_, MINB_, true>(p, maxM, st, what);    \

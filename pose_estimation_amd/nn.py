@@ -658,6 +658,42 @@ def conv2d_bwd_data_bnmask(dy: torch.Tensor, w_t: torch.Tensor, in_hw, k: int, s
     return out, rows.value
 
 
+def conv2d_bwd_data_resmask(dy: torch.Tensor, w_t: torch.Tensor, in_hw, k: int, stride: int,
+                            pad: int, residual: Optional[torch.Tensor], act: torch.Tensor,
+                            z: torch.Tensor, ws: torch.Tensor,
+                            out: Optional[torch.Tensor] = None):
+    """conv2d_bwd_data (+ residual) whose result is the whole gradient of the residual-layer
+    output `act` = relu(bn(z) + identity): stores it masked by act > 0 and leaves the partial rows
+    of batch-norm backward's two sums in `ws`; returns (g, rows) for bn_bwd_from_partials."""
+    _check_act(dy, "dy")
+    _check_act(z, "z")
+    _check_act(act, "act")
+    B, Ho, Wo, Cout = dy.shape
+    Cin = w_t.shape[0]
+    H, W = in_hw
+    for name, t in (("z", z), ("act", act), ("residual", residual)):
+        if t is not None and tuple(t.shape) != (B, H, W, Cin):
+            raise ValueError(f"{name} must be [B,H,W,Cin] = {(B, H, W, Cin)}")
+    if residual is not None:
+        _check_act(residual, "residual")
+    if Cout in (8, 16, 32):
+        nslots = narrow_bwd_layout(k, stride, pad, Cout)[2]
+        if tuple(w_t.shape) != (Cin, nslots, 64) or w_t.dtype != BF16:
+            raise ValueError(f"narrow w_t must be bfloat16 [Cin, {nslots}, 64]")
+    elif tuple(w_t.shape) != (Cin, k * k, Cout) or w_t.dtype != BF16:
+        raise ValueError("w_t must be bfloat16 [Cin, k*k, Cout]")
+    if out is None:
+        out = torch.empty((B, H, W, Cin), dtype=BF16, device=dy.device)
+    d = ConvDesc(B, H, W, Cin, Cout, k, k, stride, pad, 0, 0)
+    rows = ctypes.c_int32(0)
+    with on_device(dy):
+        check(lib().pe_conv2d_bwd_data_resmask_bf16(
+            ctypes.addressof(d), dy.data_ptr(), w_t.data_ptr(), _ptr(residual), act.data_ptr(),
+            z.data_ptr(), out.data_ptr(), ws.data_ptr(), ws.numel(), ctypes.byref(rows),
+            _stream(dy)))
+    return out, rows.value
+
+
 def deconv4x4s2_bwd_data_bnmask(dy: torch.Tensor, w_t: torch.Tensor, z: torch.Tensor,
                                 act_scale: torch.Tensor, act_shift: torch.Tensor,
                                 ws: torch.Tensor, relu: int = 1,

@@ -65,6 +65,10 @@ class TrainablePoseResNet(PoseResNet):
         # backward-data GEMMs mask their result and reduce it for the batch norm below them
         # (PE_FUSE_BN_BWD=0: the separate reduction pass, for comparison)
         self.fuse_bn_bwd = os.environ.get("PE_FUSE_BN_BWD", "1") != "0"
+        # ... and the residual layers: conv1's backward-data GEMM of a block makes the whole
+        # gradient of the block input, masks it with the stored activation and reduces it for the
+        # conv3 batch norm of the block below (PE_FUSE_RES_BWD=0: the separate reduction pass)
+        self.fuse_res_bwd = self.fuse_bn_bwd and os.environ.get("PE_FUSE_RES_BWD", "1") != "0"
         # Weight gradients run on their own stream: they depend only on a layer's input and its
         # output gradient, nothing downstream reads them before the optimizer, and at batch 64
         # many backward kernels leave CUs idle, so they fill in beside the backward-data chain.
@@ -208,15 +212,29 @@ class TrainablePoseResNet(PoseResNet):
         z3, out = self._conv_bn(b.c3, a2, residual=idn, relu=True)
         return dict(x=x, z1=z1, a1=a1, z2=z2, a2=a2, z3=z3, zd=zd, out=out)
 
-    def block_backward(self, b, s: dict, dout: torch.Tensor, flush: bool = True) -> torch.Tensor:
+    def block_backward(self, b, s: dict, dout, flush: bool = True, below=None):
         """Backward of block_forward: accumulates the block's parameter gradients into the
         gradient arena and returns the gradient with respect to the block input.  flush=False
-        leaves the block's weight gradients queued for a batched launch with later layers'."""
+        leaves the block's weight gradients queued for a batched launch with later layers'.
+
+        below = (conv3 spec, z3) of the block whose output is this block's input: the block's last
+        backward-data GEMM then makes that output's whole gradient (its own result plus the
+        identity path's), masks it with the stored activation and leaves conv3's batch-norm sums
+        behind; the return value is (g, rows) and is what the block below takes as `dout`."""
         self._join_transposes()
         x = s["x"]
         hw_in = tuple(x.shape[1:3])
         hw_mid = tuple(s["a1"].shape[1:3])
-        dz3, g3 = self._bn_bwd(b.c3, dout, s["out"], s["z3"], want_masked=True)
+        if isinstance(dout, tuple):      # masked and summed by the block above (see `below`)
+            g3, rows3 = dout
+            buf = self.bn_rows[b.c3.name]
+            dz3 = pnn.bn_bwd_from_partials(g3, s["z3"], rows3, self._gamma(b.c3), buf[0], buf[1],
+                                           self._g(b.c3.name + ".bn.gamma"),
+                                           self._g(b.c3.name + ".bn.beta"),
+                                           self._workspace(s["z3"]), frozen=self.freeze_bn,
+                                           sync=self.bn_sync)
+        else:
+            dz3, g3 = self._bn_bwd(b.c3, dout, s["out"], s["z3"], want_masked=True)
         if b.down:
             dzd, _ = self._bn_bwd(b.down, g3, None, s["zd"])
             # the arena holds `down` after conv3, so it is finished before conv3 is marked
@@ -240,6 +258,10 @@ class TrainablePoseResNet(PoseResNet):
         self._weight_grad(b.c1, x, dz1, 1, 1, 0)
         if flush:
             self._flush_weight_grads()
+        if below is not None:
+            _, z3_below = below
+            return pnn.conv2d_bwd_data_resmask(dz1, self.wt[b.c1.name], hw_in, 1, 1, 0, res, x,
+                                               z3_below, self._workspace(z3_below))
         return pnn.conv2d_bwd_data(dz1, self.wt[b.c1.name], hw_in, 1, 1, 0, residual=res)
 
     def deconv_forward(self, d, x: torch.Tensor) -> dict:
@@ -400,8 +422,11 @@ class TrainablePoseResNet(PoseResNet):
                 dx = pnn.deconv4x4s2_bwd_data(dz, self.wt[d.name])
                 dz = None
         # bottleneck blocks
-        for b, s in zip(reversed(blocks), reversed(sv["blocks"])):
-            dx = self.block_backward(b, s, dx, flush=False)
+        for i in reversed(range(len(blocks))):
+            # the block's last GEMM also starts the batch-norm backward of the block below it
+            below = ((blocks[i - 1].c3, sv["blocks"][i - 1]["z3"])
+                     if i > 0 and self.fuse_res_bwd else None)
+            dx = self.block_backward(blocks[i], sv["blocks"][i], dx, flush=False, below=below)
         # stem
         da0 = pnn.maxpool3x3s2_bwd(sv["pool_idx"], dx)
         dz0, _ = self._bn_bwd(stem, da0, sv["a0"], sv["z0"], rebuild=True)

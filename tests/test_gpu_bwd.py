@@ -613,6 +613,49 @@ def test_bwd_data_with_fused_mask_and_sums_equals_the_separate_passes(case):
     _check_fused(g_f, dz_f, dg_f, db_f, g_r, dz_r, dg_r, db_r)
 
 
+RESMASK_CASES = [
+    # B, H, W, Cin, Cout, k, stride, pad, with residual
+    (2, 16, 12, 256, 64, 1, 1, 0, True),      # conv1 of a bottleneck -> the block below's conv3
+    (3, 16, 12, 512, 128, 1, 1, 0, True),
+    (2, 8, 6, 2048, 512, 1, 1, 0, True),      # few tiles: 64 x 64 double buffer
+    (3, 16, 12, 64, 64, 3, 1, 1, True),       # basic block: 3x3 conv1
+    (2, 24, 20, 32, 32, 3, 1, 1, True),       # narrow branch of the multi-branch net
+    (3, 16, 12, 128, 128, 3, 2, 1, False),    # stride 2, no residual
+    (5, 64, 48, 256, 64, 1, 1, 0, True),      # many tiles
+]
+
+
+@pytest.mark.parametrize("case", RESMASK_CASES)
+def test_bwd_data_with_residual_and_stored_activation_mask(case):
+    """The gradient of a residual layer's output act = relu(bn(z) + identity), made by the last of
+    its consumers: backward-data + residual, masked by act > 0, with batch-norm backward's sums,
+    against pe_conv2d_bwd_data_bf16(residual) followed by pe_bn_bwd_bf16(a = act)."""
+    B, H, W, Cin, Cout, k, s, p, with_res = case
+    g = torch.Generator().manual_seed(67 + sum(case[:8]))
+    Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    z = rnd((B, H, W, Cin), g).to(BF16).cuda()
+    ident = rnd((B, H, W, Cin), g).to(BF16).cuda()
+    res = rnd((B, H, W, Cin), g).to(BF16).cuda() if with_res else None
+    dy = rnd((B, Ho, Wo, Cout), g).to(BF16).cuda()
+    w = rnd((Cout, Cin, k, k), g, (1.0 / (Cout * k * k)) ** 0.5)
+    w_t = planned_wt(w, k, s, p) if Cout in (8, 16, 32) else conv_wt(w)
+    gamma, mean, rstd, scale, shift, ws = _bn_rows(z, Cin, g)
+    act = pnn.bn_apply(z, scale, shift, ident, relu=1)
+    da = pnn.conv2d_bwd_data(dy, w_t, (H, W), k, s, p, residual=res)
+    dg_r, db_r = torch.empty(Cin, device="cuda"), torch.empty(Cin, device="cuda")
+    dz_r, g_r = pnn.bn_bwd(da, act, z, gamma, mean, rstd, dg_r, db_r, ws, want_masked=True)
+    g_r, dz_r = g_r.clone(), dz_r.clone()
+    frac = (g_r == 0).float().mean().item()
+    assert 0.15 < frac < 0.9
+    ws2 = pnn.bn_workspace(B * H * W, Cin, "cuda")
+    ws2.fill_(0xFF)
+    dg_f, db_f = torch.empty(Cin, device="cuda"), torch.empty(Cin, device="cuda")
+    g_f, rows = pnn.conv2d_bwd_data_resmask(dy, w_t, (H, W), k, s, p, res, act, z, ws2)
+    assert rows >= 1
+    dz_f = pnn.bn_bwd_from_partials(g_f, z, rows, gamma, mean, rstd, dg_f, db_f, ws2)
+    _check_fused(g_f, dz_f, dg_f, db_f, g_r, dz_r, dg_r, db_r)
+
+
 @pytest.mark.parametrize("case", [(2, 8, 6, 256, 256), (3, 16, 12, 512, 256)])
 def test_deconv_bwd_data_with_fused_mask_and_sums(case):
     B, H, W, Cin, Cout = case
