@@ -91,7 +91,7 @@ class Layer:
 
 class Var:
     """An activation and, during backward, the gradient accumulated for it so far."""
-    __slots__ = ("t", "grad", "needs_grad", "consumers", "prod", "dz")
+    __slots__ = ("t", "grad", "needs_grad", "consumers", "prod", "dz", "ngrad", "prod_res")
 
     def __init__(self, t: torch.Tensor, needs_grad: bool = True):
         self.t = t
@@ -100,6 +100,8 @@ class Var:
         self.consumers = 0      # layers that read this activation in the current forward pass
         self.prod = None        # (layer, z, act) when it is act(bn(z)) with no residual
         self.dz = None          # gradient of that z, when the consumer's backward-data made it
+        self.ngrad = 0          # gradient contributions received so far in backward
+        self.prod_res = None    # (layer, z) when it is relu(bn(z) + residual)
 
 
 def _align8(n: int) -> int:
@@ -174,6 +176,9 @@ class TrainGraph:
         # backward-data GEMMs mask their result and reduce it for the batch norm below them
         # whenever that layer's output has no other reader (PE_FUSE_BN_BWD=0: separate passes)
         self.fuse_bn_bwd = os.environ.get("PE_FUSE_BN_BWD", "1") != "0"
+        # ... and for residual layers whenever the last reader of their output is such a GEMM
+        # (PE_FUSE_RES_BWD=0: the separate reduction pass)
+        self.fuse_res_bwd = self.fuse_bn_bwd and os.environ.get("PE_FUSE_RES_BWD", "1") != "0"
         self.freeze_bn = False
         # PE_BN_FUSED=1: finalize + element-wise pass of every batch norm as ONE launch (an
         # in-launch hand-off between workgroups; the hand-off buffer belongs to the main stream,
@@ -396,6 +401,8 @@ class TrainGraph:
             out = Var(pnn.bn_apply(z, scale, shift, res_t, act))
         if act and residual is None:
             out.prod = (L, z, act)
+        elif act == 1 and residual is not None:
+            out.prod_res = (L, z)
         self.tape.append(("unit", L, x, residual, act, z, out))
         return out
 
@@ -452,6 +459,7 @@ class TrainGraph:
         if not v.needs_grad:
             return
         v.grad = g if v.grad is None else pnn.add_bf16(v.grad, g)
+        v.ngrad += 1
 
     WGRAD_BATCH = 8   # weight gradients handed to the side stream per fork
 
@@ -488,9 +496,29 @@ class TrainGraph:
         if not x.needs_grad:
             return
         hw = tuple(x.t.shape[1:3])
+        x.ngrad += 1
         if L.kind == "dw":
             dx = pnn.depthwise3x3_bwd_data(dz, self.w(L), hw, L.stride, L.dilation)
             x.grad = dx if x.grad is None else pnn.add_bf16(x.grad, dx)
+            return
+        if (self.fuse_res_bwd and x.prod_res is not None and x.ngrad == x.consumers
+                and L.k * L.k * L.cout >= self.fuse_min_k
+                and not (L.k == 1 and L.stride == 2)
+                and hw[0] % L.stride == 0 and hw[1] % L.stride == 0):
+            # x = relu(bn(z) + identity) and this is the last of its readers to be differentiated:
+            # the GEMM adds what the others left, masks the sum with the stored activation and
+            # reduces batch-norm backward's sums, so the residual layer below gets its dz (and
+            # the identity path its masked gradient) without a reduction pass over the gradient
+            Lb, zb = x.prod_res
+            buf = self.bn_rows[Lb.name]
+            ws = self._workspace_for(zb.numel() // Lb.cout, Lb.cout)
+            g, rows = pnn.conv2d_bwd_data_resmask(dz, self.wt[L.name], hw, L.k, L.stride, L.pad,
+                                                  x.grad, x.t, zb, ws)
+            x.dz = pnn.bn_bwd_from_partials(
+                g, zb, rows, self.view(self.master, Lb.name + ".bn.gamma"), buf[0], buf[1],
+                self._g(Lb.name + ".bn.gamma"), self._g(Lb.name + ".bn.beta"), ws,
+                frozen=self.freeze_bn, sync=self._sync())
+            x.grad = g
             return
         if (self.fuse_bn_bwd and x.prod is not None and x.consumers == 1 and x.grad is None
                 and L.k * L.k * L.cout >= self.fuse_min_k
@@ -537,6 +565,7 @@ class TrainGraph:
                     hw = tuple(x.t.shape[1:3])
                     x.grad = pnn.conv2d_bwd_data(dyp, self.wt[L.name], hw, 1, 1, 0,
                                                  residual=x.grad)
+                    x.ngrad += 1
             elif rec[0] == "fuse":
                 _, base, lows, facs, relu, out = rec
                 if out.grad is None:
@@ -553,6 +582,8 @@ class TrainGraph:
                 if out.dz is not None:       # made by the consumer's backward-data GEMM
                     dz = out.dz
                     out.dz = None
+                    if residual is not None:     # out.grad is the masked gradient here
+                        self._acc(residual, out.grad)
                     out.grad = None
                     self._weight_grad(L, x.t, dz)
                     if L.kind != "stem3":
