@@ -869,6 +869,9 @@ def main() -> None:
     if rank == 0:
         out = {
             "metric": METRIC,
+            # `value` counts images of the workload named in config.workload (for decode: batches
+            # of 17 heat maps per image); the network images/s of the metric are under "also"
+            "value_of": f"{wl.name}: images/s of this workload over all ranks",
             "value": world * wl.batch * args.steps / elapsed,
             "unit": "images/s" if args.workload != "adam" else "steps/s",
             "n_gpus": world,
