@@ -274,7 +274,10 @@ __global__ __launch_bounds__(256) void depthwise3x3_bwd_data_kernel(
 // walks a contiguous range of output cells, thread (row lane, channel group) keeping 9 x 8
 // float32 sums, folds its row lanes through LDS in lane order and writes one partial
 // [9][C] block; the second kernel adds the blocks in order and accumulates into dw.
-constexpr int kDwMaxBlocks = 512;
+// 512 partial blocks (two workgroups per CU) measured best beside the main chain of the
+// MobileNetV2 step: 256 / 512 / 1024 / 2048 -> 15.97 / 15.83 / 16.07 / 16.35 ms.
+constexpr int kDwMaxBlocks = 512;    // the workspace is sized for this many partial blocks
+constexpr int kDwBlocks = 512;
 
 __global__ __launch_bounds__(256) void depthwise3x3_bwd_weight_kernel(
     const uint16_t* __restrict__ x, const uint16_t* __restrict__ dy, int B, int H, int W, int C,
@@ -295,11 +298,16 @@ __global__ __launch_bounds__(256) void depthwise3x3_bwd_weight_kernel(
 #pragma unroll
         for (int i = 0; i < 8; ++i) acc[t][i] = 0.0f;
     if (rli < rl) {
+        // (image, row, column) of this thread's first cell; the next one lies rl cells on, which
+        // is a constant (image, row, column) step with one carry per digit: the loop divides
+        // nothing (three 64-bit divisions per cell cost more than the cell's 72 multiply-adds)
+        const int HoWo = Ho * Wo;
+        long mm = m0 + rli;
+        int b = (int)(mm / HoWo);
+        int rem = (int)(mm - (long)b * HoWo);
+        int oy = rem / Wo, ox = rem - (rem / Wo) * Wo;
+        const int sb = rl / HoWo, sy = (rl % HoWo) / Wo, sx = (rl % HoWo) % Wo;
         for (long m = m0 + rli; m < m1; m += rl) {
-            const int ox = (int)(m % Wo);
-            const long r = m / Wo;
-            const int oy = (int)(r % Ho);
-            const long b = r / Ho;
             float gf[8];
             dw_unpack(*reinterpret_cast<const uint4*>(dy + (m * C8 + cgi) * 8), gf);
             uint4 xv[9];
@@ -310,7 +318,7 @@ __global__ __launch_bounds__(256) void depthwise3x3_bwd_weight_kernel(
                 for (int kx = 0; kx < 3; ++kx) {
                     const int ix = ox * stride + (kx - 1) * dil;
                     const bool ok = (unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W;
-                    const long off = ok ? (((b * H + iy) * W + ix) * (long)C8 + cgi) * 8 : (long)cgi * 8;
+                    const long off = ok ? ((long)((b * H + iy) * W + ix) * C8 + cgi) * 8 : (long)cgi * 8;
                     uint4 v = *reinterpret_cast<const uint4*>(x + off);
                     if (!ok) v = make_uint4(0u, 0u, 0u, 0u);
                     xv[ky * 3 + kx] = v;
@@ -323,6 +331,13 @@ __global__ __launch_bounds__(256) void depthwise3x3_bwd_weight_kernel(
 #pragma unroll
                 for (int i = 0; i < 8; ++i) acc[t][i] += gf[i] * xf[i];
             }
+            ox += sx;
+            const int cx = ox >= Wo ? 1 : 0;
+            ox -= cx ? Wo : 0;
+            oy += sy + cx;
+            const int cy = oy >= Ho ? 1 : 0;
+            oy -= cy ? Ho : 0;
+            b += sb + cy;
         }
 #pragma unroll
         for (int t = 0; t < 9; ++t)
@@ -423,6 +438,8 @@ extern "C" int32_t pe_depthwise3x3_bwd_weight_bf16(const void* x, const void* dy
     const int32_t rc = dw_check(what, B, H, W, C, stride, dilation);
     if (rc != PE_OK) return rc;
     PE_REQUIRE(C <= 2048, PE_E_UNSUPPORTED, "%s: at most 2048 channels", what);
+    PE_REQUIRE((long)B * H * W < 0x7fffffffL, PE_E_UNSUPPORTED, "%s: pixel count does not fit int32",
+               what);
     PE_REQUIRE(aligned(x, 16) && aligned(dy, 16) && aligned(workspace, 16), PE_E_INVALID,
                "%s: tensors must be 16-byte aligned", what);
     const int Ho = (H - 1) / stride + 1, Wo = (W - 1) / stride + 1;
@@ -433,7 +450,10 @@ extern "C" int32_t pe_depthwise3x3_bwd_weight_bf16(const void* x, const void* dy
     const int rl_lds = (int)((64 * 1024) / ((size_t)9 * C * sizeof(float)));
     if (rl > rl_lds) rl = rl_lds;
     PE_REQUIRE(rl >= 1, PE_E_UNSUPPORTED, "%s: too many channels for the fold", what);
-    long cells = (M + kDwMaxBlocks - 1) / kDwMaxBlocks;
+    static const char* tune = getenv("PE_DW_WGRAD_BLOCKS");   // tuning aid, at most kDwMaxBlocks
+    long nb = tune ? atol(tune) : kDwBlocks;
+    if (nb < 1 || nb > kDwMaxBlocks) nb = kDwBlocks;
+    long cells = (M + nb - 1) / nb;
     if (cells < (long)rl * 8) cells = (long)rl * 8;
     const int nblk = (int)((M + cells - 1) / cells);
     PE_REQUIRE((size_t)nblk * 9 * C * sizeof(float) <= workspace_bytes, PE_E_INVALID,
