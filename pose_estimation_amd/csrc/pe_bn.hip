@@ -274,8 +274,14 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const uint16_t* __restric
                                                        const float* __restrict__ shift,
                                                        const uint16_t* __restrict__ res, int relu,
                                                        uint16_t* __restrict__ y) {
+    // the chunk's channel group is carried along the grid-stride loop (one 64-bit modulo per
+    // thread instead of one per chunk)
+    const int cstep = (int)(((long)gridDim.x * 256) % cg);
+    int cgi = (int)(((long)blockIdx.x * 256 + threadIdx.x) % cg);
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nchunk; i += (long)gridDim.x * 256) {
-        const int c0 = (int)(i % cg) * 8;
+        const int c0 = cgi * 8;
+        cgi += cstep;
+        cgi -= cgi >= cg ? cg : 0;
         float v[8];
         unpack8(*reinterpret_cast<const uint4*>(z + i * 8), v);
         const f32x4 s0 = *reinterpret_cast<const f32x4*>(scale + c0);
@@ -310,8 +316,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
     const float* __restrict__ coefB, const float* __restrict__ coefC, float act_hi,
     const float* __restrict__ msc, const float* __restrict__ msh,
     uint16_t* __restrict__ dz, uint16_t* __restrict__ dmasked) {
+    const int cstep = (int)(((long)gridDim.x * 256) % cg);
+    int cgi = (int)(((long)blockIdx.x * 256 + threadIdx.x) % cg);
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nchunk; i += (long)gridDim.x * 256) {
-        const int c0 = (int)(i % cg) * 8;
+        const int c0 = cgi * 8;
+        cgi += cstep;
+        cgi -= cgi >= cg ? cg : 0;
         float g[8], zf[8];
         unpack8(*reinterpret_cast<const uint4*>(da + i * 8), g);
         unpack8(*reinterpret_cast<const uint4*>(z + i * 8), zf);

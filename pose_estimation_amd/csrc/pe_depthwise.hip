@@ -33,13 +33,26 @@ __global__ __launch_bounds__(256) void depthwise3x3_kernel(const uint16_t* __res
                                                            int Ho, int Wo) {
     const int C8 = C >> 3;
     const long total = (long)B * Ho * Wo * C8;
+    const bool small = total < 0x7fffffffL;   // uniform: 32-bit index split (a quarter of the cost)
     for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
-        const int c8 = (int)(e % C8);
-        long r = e / C8;
-        const int ox = (int)(r % Wo);
-        r /= Wo;
-        const int oy = (int)(r % Ho);
-        const long b = r / Ho;
+        int c8, ox, oy;
+        long b;
+        if (small) {
+            const unsigned eu = (unsigned)e;
+            c8 = (int)(eu % (unsigned)C8);
+            unsigned r = eu / (unsigned)C8;
+            ox = (int)(r % (unsigned)Wo);
+            r /= (unsigned)Wo;
+            oy = (int)(r % (unsigned)Ho);
+            b = r / (unsigned)Ho;
+        } else {
+            c8 = (int)(e % C8);
+            long r = e / C8;
+            ox = (int)(r % Wo);
+            r /= Wo;
+            oy = (int)(r % Ho);
+            b = r / Ho;
+        }
         float acc[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) acc[i] = 0.0f;
@@ -125,12 +138,24 @@ __global__ __launch_bounds__(256) void depthwise3x3_s1_kernel(const uint16_t* __
     const long total = (long)B * nty * ntx * C4;
     const long e = (long)blockIdx.x * 256 + threadIdx.x;
     if (e >= total) return;
-    const int c4 = (int)(e % C4);
-    long r = e / C4;
-    const int tx = (int)(r % ntx);
-    r /= ntx;
-    const int ty = (int)(r % nty);
-    const long b = r / nty;
+    int c4, tx, ty;
+    long b;
+    if (total < 0x7fffffffL) {   // uniform: 32-bit index split
+        const unsigned eu = (unsigned)e;
+        c4 = (int)(eu % (unsigned)C4);
+        unsigned r = eu / (unsigned)C4;
+        tx = (int)(r % (unsigned)ntx);
+        r /= (unsigned)ntx;
+        ty = (int)(r % (unsigned)nty);
+        b = r / (unsigned)nty;
+    } else {
+        c4 = (int)(e % C4);
+        long r = e / C4;
+        tx = (int)(r % ntx);
+        r /= ntx;
+        ty = (int)(r % nty);
+        b = r / nty;
+    }
     const int rx = tx % dil, X0 = (tx / dil) * DW_TX;
     const int ry = ty % dil, Y0 = (ty / dil) * DW_TY;
 
@@ -225,13 +250,26 @@ __global__ __launch_bounds__(256) void depthwise3x3_bwd_data_kernel(
     const uint16_t* __restrict__ w, uint16_t* __restrict__ dx, int Ho, int Wo) {
     const int C8 = C >> 3;
     const long total = (long)B * H * W * C8;
+    const bool small = total < 0x7fffffffL;   // uniform: 32-bit index split (a quarter of the cost)
     for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
-        const int c8 = (int)(e % C8);
-        long r = e / C8;
-        const int ix = (int)(r % W);
-        r /= W;
-        const int iy = (int)(r % H);
-        const long b = r / H;
+        int c8, ix, iy;
+        long b;
+        if (small) {
+            const unsigned eu = (unsigned)e;
+            c8 = (int)(eu % (unsigned)C8);
+            unsigned r = eu / (unsigned)C8;
+            ix = (int)(r % (unsigned)W);
+            r /= (unsigned)W;
+            iy = (int)(r % (unsigned)H);
+            b = r / (unsigned)H;
+        } else {
+            c8 = (int)(e % C8);
+            long r = e / C8;
+            ix = (int)(r % W);
+            r /= W;
+            iy = (int)(r % H);
+            b = r / H;
+        }
         uint4 gv[9];
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
