@@ -50,7 +50,7 @@ class TrainablePoseResNet(PoseResNet):
         self.bn_buf = {c.name: torch.empty(4, c.cout, dtype=torch.float32, device=dev)
                        for c in self.convs if c.bn}
         self.bn_rows = {k: tuple(v.unbind(0)) for k, v in self.bn_buf.items()}
-        self._ws: Optional[torch.Tensor] = None
+        self._ws: Dict[int, torch.Tensor] = {}     # batch-norm workspace, one per stream
         self._tplan = None
         stem = self.specs[0]
         self.stem_mask = pnn.pack_stem_weight(torch.ones(stem.cout, 3, 7, 7)).float().to(dev)
@@ -62,6 +62,11 @@ class TrainablePoseResNet(PoseResNet):
         self._recorded: Dict[tuple, "replay.RecordedPass"] = {}
         self._keep: list = []
         self._pending_wg: list = []
+        # the projection of a block's identity path runs beside the block's main chain: forward
+        # on the weight-gradient stream (idle then), backward on a stream of its own
+        self.down_beside = os.environ.get("PE_TRAIN_DOWN_BESIDE", "1") != "0"
+        self.down_stream = torch.cuda.Stream(device=dev)
+        self._down_unjoined = False
         # backward-data GEMMs mask their result and reduce it for the batch norm below them
         # (PE_FUSE_BN_BWD=0: the separate reduction pass, for comparison)
         self.fuse_bn_bwd = os.environ.get("PE_FUSE_BN_BWD", "1") != "0"
@@ -160,10 +165,15 @@ class TrainablePoseResNet(PoseResNet):
         return self._workspace_for(z.numel() // C, C)
 
     def _workspace_for(self, M: int, C: int) -> torch.Tensor:
+        """Scratch for batch-norm partial sums, one buffer per stream: a conv's rows must survive
+        until the finalize behind it on the same stream has read them."""
         need = pnn.lib().pe_bn_workspace_bytes(M, C)
-        if self._ws is None or self._ws.numel() < need:
-            self._ws = torch.empty(max(need, 1 << 24), dtype=torch.uint8, device=self.device)
-        return self._ws
+        key = torch.cuda.current_stream(self.device).cuda_stream
+        ws = self._ws.get(key)
+        if ws is None or ws.numel() < need:
+            ws = self._ws[key] = torch.empty(max(need, 1 << 24), dtype=torch.uint8,
+                                             device=self.device)
+        return ws
 
     def _gamma(self, c: ConvSpec):
         return self.view(self.master, c.name + ".bn.gamma")
@@ -175,19 +185,23 @@ class TrainablePoseResNet(PoseResNet):
         return self.view(self.grads, name)
 
     # ------------------------------------------------------------------ forward (batch stats)
-    def _bn(self, c: ConvSpec, z: torch.Tensor, rows: int, residual=None, relu=True) -> torch.Tensor:
-        """Normalises z with the batch statistics its conv left in the workspace as `rows`
-        partial rows.  The workspace is shared, so this must run before the next conv."""
+    def _bn(self, c: ConvSpec, z: torch.Tensor, rows: int, residual=None, relu=True,
+            ws: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Normalises z with the batch statistics its conv left in the workspace `ws` as `rows`
+        partial rows.  The workspace is shared by the stream's layers, so this must run before
+        the next conv on the same stream."""
         C = z.shape[3]
+        if ws is None:
+            ws = self._workspace_for(z.numel() // C, C)
         if self.freeze_bn:     # rows hold the running statistics (see _refresh_frozen_rows)
             r = self.bn_rows[c.name]
             return pnn.bn_apply(z, r[2], r[3], residual, relu)
         if self.bn_sync is not None:
-            return pnn.bn_finalize_apply(self._ws, rows, z, self._gamma(c), self._beta(c), BN_EPS,
+            return pnn.bn_finalize_apply(ws, rows, z, self._gamma(c), self._beta(c), BN_EPS,
                                          self.bn_momentum, self.bn_mean[c.name],
                                          self.bn_var[c.name], self.bn_rows[c.name], self.bn_sync,
                                          residual, relu)
-        _, _, scale, shift = pnn.bn_finalize(self._ws, rows, z.numel() // C, C, self._gamma(c),
+        _, _, scale, shift = pnn.bn_finalize(ws, rows, z.numel() // C, C, self._gamma(c),
                                              self._beta(c), BN_EPS, self.bn_momentum,
                                              self.bn_mean[c.name], self.bn_var[c.name],
                                              out=self.bn_rows[c.name])
@@ -197,15 +211,26 @@ class TrainablePoseResNet(PoseResNet):
         B, H, W, _ = x.shape
         k = c.k
         M = B * ((H + 2 * pad - k) // stride + 1) * ((W + 2 * pad - k) // stride + 1)
-        z, rows = pnn.conv2d_bnstats(x, self.w(c), self._workspace_for(M, c.cout), stride, pad)
-        return z, self._bn(c, z, rows, residual, relu)
+        ws = self._workspace_for(M, c.cout)
+        z, rows = pnn.conv2d_bnstats(x, self.w(c), ws, stride, pad)
+        return z, self._bn(c, z, rows, residual, relu, ws)
 
     def block_forward(self, b, x: torch.Tensor) -> dict:
         """One bottleneck block with batch statistics; returns everything backward needs."""
+        zd = None
+        side = self.wgrad_stream if (b.down and self.down_beside and self.bn_sync is None) else None
+        if side is not None:
+            # the projection of the identity path depends on the block input alone: it runs on the
+            # weight-gradient stream (idle during forward) beside conv1 and conv2
+            main = torch.cuda.current_stream(self.device)
+            replay.wait_stream(side, main)
+            with torch.cuda.stream(side):
+                zd, idn = self._conv_bn(b.down, x, stride=b.down.stride, relu=False)
         z1, a1 = self._conv_bn(b.c1, x)
         z2, a2 = self._conv_bn(b.c2, a1, stride=b.c2.stride, pad=1)
-        zd = None
-        if b.down:
+        if side is not None:
+            replay.wait_stream(main, side)
+        elif b.down:
             zd, idn = self._conv_bn(b.down, x, stride=b.down.stride, relu=False)
         else:
             idn = x
@@ -235,7 +260,18 @@ class TrainablePoseResNet(PoseResNet):
                                            sync=self.bn_sync)
         else:
             dz3, g3 = self._bn_bwd(b.c3, dout, s["out"], s["z3"], want_masked=True)
-        if b.down:
+        dside = self.down_stream if (b.down and self.down_beside and self.bn_sync is None) else None
+        if dside is not None:
+            # the projection's backward needs g3 alone and is needed by the block's last GEMM
+            main = torch.cuda.current_stream(self.device)
+            replay.wait_stream(dside, main)
+            with torch.cuda.stream(dside):
+                dzd, _ = self._bn_bwd(b.down, g3, None, s["zd"])
+                res = pnn.conv2d_bwd_data(dzd, self.wt[b.down.name], hw_in, 1, b.down.stride, 0)
+            self._down_unjoined = True     # weight-gradient launches wait for it (see _beside)
+            self._weight_grad(b.down, x, dzd, 1, b.down.stride, 0)
+            self._weight_grad(b.c3, s["a2"], dz3, 1, 1, 0)
+        elif b.down:
             dzd, _ = self._bn_bwd(b.down, g3, None, s["zd"])
             # the arena holds `down` after conv3, so it is finished before conv3 is marked
             self._weight_grad(b.down, x, dzd, 1, b.down.stride, 0)
@@ -258,6 +294,9 @@ class TrainablePoseResNet(PoseResNet):
         self._weight_grad(b.c1, x, dz1, 1, 1, 0)
         if flush:
             self._flush_weight_grads()
+        if dside is not None:
+            replay.wait_stream(main, dside)
+            self._down_unjoined = False
         if below is not None:
             _, z3_below = below
             return pnn.conv2d_bwd_data_resmask(dz1, self.wt[b.c1.name], hw_in, 1, 1, 0, res, x,
@@ -382,6 +421,8 @@ class TrainablePoseResNet(PoseResNet):
             yield
             return
         replay.wait_stream(side, torch.cuda.current_stream(self.device))
+        if self._down_unjoined:    # a projection's dz and batch-norm gradients are still on their way
+            replay.wait_stream(side, self.down_stream)
         # kept alive until backward has joined the streams: cheaper for the host than telling the
         # allocator per tensor (record_stream; 8.71 against 8.80 ms per step), and it is what a
         # recorded pass needs, which replays the allocator's decisions as well

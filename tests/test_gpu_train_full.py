@@ -94,3 +94,23 @@ def test_full_resnet50_batch64_step():
     assert all(np.isfinite(runs[0])) and runs[0][-1] < runs[0][0]
     assert runs[0] == runs[1], "the step is not reproducible bit for bit"
     assert torch.equal(masters[0], masters[1])
+
+
+def test_projection_beside_the_main_chain_changes_nothing():
+    """The identity path's projection runs on side streams (forward beside conv1 and conv2,
+    backward beside conv3..conv1); the same kernels on one stream must give the same bits."""
+    img, j_np, m_np = _batch()
+    joints = torch.from_numpy(j_np).cuda()
+    mask = torch.from_numpy(m_np).cuda()
+    out = []
+    for beside in (True, False):
+        net = _net()
+        net.down_beside = beside
+        losses = [net.train_step(img, joints, mask, lr=1e-3)[0].item() for _ in range(2)]
+        torch.cuda.synchronize()
+        out.append((losses, net.master.clone(), {k: v.clone() for k, v in net.bn_mean.items()}))
+        del net
+    assert out[0][0] == out[1][0]
+    assert torch.equal(out[0][1], out[1][1])
+    for k in out[0][2]:
+        assert torch.equal(out[0][2][k], out[1][2][k]), k
