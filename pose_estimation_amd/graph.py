@@ -462,13 +462,17 @@ class TrainGraph:
         v.ngrad += 1
 
     WGRAD_BATCH = 8   # weight gradients handed to the side stream per fork
+    WGRAD_TAIL = int(os.environ.get("PE_WGRAD_TAIL", "10"))   # tape records that count as the end
 
     def _weight_grad(self, L: Layer, x: torch.Tensor, dz: torch.Tensor, cout=None) -> None:
         """Queues a layer's weight gradient.  Forking to the side stream costs the host an event
         record, a wait and two stream switches; done per layer that is a third of the time it
         takes to enqueue a step of a 300-layer network, so the forks are batched."""
         self._pending_wg.append((L, x, dz, cout))
-        if len(self._pending_wg) >= self.WGRAD_BATCH:
+        # the last layers of the pass fork in pairs: whatever is still queued when the main chain
+        # ends runs behind it, with nothing beside it
+        limit = self.WGRAD_BATCH if len(self.tape) >= self.WGRAD_TAIL else 2
+        if len(self._pending_wg) >= limit:
             self._flush_weight_grads()
 
     def _flush_weight_grads(self) -> None:

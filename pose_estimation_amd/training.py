@@ -468,11 +468,12 @@ class TrainablePoseResNet(PoseResNet):
             below = ((blocks[i - 1].c3, sv["blocks"][i - 1]["z3"])
                      if i > 0 and self.fuse_res_bwd else None)
             dx = self.block_backward(blocks[i], sv["blocks"][i], dx, flush=False, below=below)
-        # stem
+        # stem.  The blocks' last weight gradients go out first, so that they run beside the
+        # pooling and batch-norm backward instead of behind them.
+        self._flush_weight_grads()
         da0 = pnn.maxpool3x3s2_bwd(sv["pool_idx"], dx)
         dz0, _ = self._bn_bwd(stem, da0, sv["a0"], sv["z0"], rebuild=True)
         gw = self._g(stem.name + ".weight")
-        self._flush_weight_grads()
         with self._beside(sv["xs"], dz0):
             pnn.stem7x7s2_bwd_weight(sv["xs"], dz0, gw)
             pnn.mul_(gw, self.stem_mask)
