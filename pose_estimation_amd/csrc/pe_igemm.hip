@@ -820,7 +820,17 @@ int32_t igemm_launch(const IgemmParams& pin, hipStream_t st, const char* what) {
             return launch_cfg<BM_, BN_, WM_, DB_, PF_, MINB_, true, 2, true>(p, maxM, st, what); \
         return launch_cfg<BM_, BN_, WM_, DB_, PF_, MINB_, true>(p, maxM, st, what);    \
     }
+    // The masked epilogue of the 128 x 128 tile needs some 156 registers; at four workgroups per
+    // CU (a cap of 128) it spilled 17 to 28 of them to scratch memory, which cost the ResNet-50
+    // training step 4 % (8.08 against 7.74 ms).  Three per CU fit without spilling; two measured
+    // the same (PE_IGEMM_MASK_MINB: 2, 3 or 4, for comparison).
+    if (p.mask_z && bm == 128 && bn == 128 && !force) {
+        static const char* mm = getenv("PE_IGEMM_MASK_MINB");
+        minb = mm ? atoi(mm) : 3;
+    }
     PE_CFG_MASK(128, 128, 2, false, false, 4)
+    PE_CFG_MASK(128, 128, 2, false, false, 3)
+    PE_CFG_MASK(128, 128, 2, false, false, 2)
     PE_CFG_MASK(128, 64, 2, false, false, 4)
     PE_CFG_MASK(64, 128, 2, false, false, 4)
     PE_CFG_MASK(64, 64, 2, false, false, 4)
