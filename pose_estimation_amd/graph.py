@@ -188,9 +188,12 @@ class TrainGraph:
         # MobileNetV2 16.13 vs 16.17 ms), so the separate finalize launch stays the default.
         self.bn_sync = pnn.bn_sync(dev) if os.environ.get("PE_BN_FUSED", "0") == "1" else None
         self._syncs: Dict[int, torch.Tensor] = {}
-        # ... when the GEMM's reduction is long enough to carry the heavier epilogue: with a
-        # short one (a pointwise conv from 64 channels) the separate pass measured faster
-        self.fuse_min_k = int(os.environ.get("PE_FUSE_MIN_K", "256"))
+        # ... for GEMMs whose reduction is at least this long.  While the masked 128 x 128 tile
+        # still spilled registers a short reduction could not carry the heavier epilogue and the
+        # threshold stood at 256; since it runs three workgroups per CU, fusing everywhere
+        # measures faster (16 against 256: HRNet-W32 32.33 against 32.64 ms, MobileNetV2 15.58
+        # against 15.80 ms)
+        self.fuse_min_k = int(os.environ.get("PE_FUSE_MIN_K", "16"))
         self._pending_wg: list = []
         # set by a network that runs branches of its forward pass on streams of their own
         self.multi_stream = False
