@@ -158,48 +158,58 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const uint16_t* __restri
     }
 }
 
-// Second reduction stage.  A workgroup folds the per-block partials of 4 channels: thread
-// (slice, ch) adds blocks slice, slice+64, ... eight at a time (eight independent loads in
-// flight: the stage is latency-bound), then the 64 slices are added in order by the threads of
-// slice 0, which return their channel (every other thread returns -1).  The order of additions
-// is fixed by (nblk, C) alone.  Launch with C/4 workgroups of 256 threads.
+// Second reduction stage.  A workgroup folds the per-block partials of 4 channels with all of
+// its 256 threads: thread t adds blocks t, t+256, ... eight at a time (the stage is bound by
+// latency, so every load a thread will ever need is in flight after one or two rounds: a 16-byte
+// load per sum covers the 4 channels), the 64 lane sums of a wave are added by a butterfly of
+// lane exchanges and the four wave sums through LDS by threads 0..3, which return their
+// channel (every other thread returns -1).  The order of additions is fixed by (nblk, C) alone.
+// Launch with C/4 workgroups of 256 threads; C is a multiple of 8 and the rows 16-byte aligned.
 constexpr int kFoldCh = 4;
-constexpr int kFoldSlices = 64;
 constexpr int kFoldUnroll = 8;
+
+__device__ __forceinline__ float wave_butterfly_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);   // same value in every lane
+    return v;
+}
+
 __device__ __forceinline__ int fold_partials(const float* __restrict__ partial, int nblk, int C,
                                              float& s1, float& s2) {
-    __shared__ float red[2][kFoldSlices][kFoldCh + 1];
-    const int ch = threadIdx.x & (kFoldCh - 1);
-    const int slice = threadIdx.x / kFoldCh;
-    const int c = blockIdx.x * kFoldCh + ch;
-    float a1 = 0.0f, a2 = 0.0f;
-    if (c < C) {
-        for (int b0 = slice; b0 < nblk; b0 += kFoldSlices * kFoldUnroll) {
-            float v1[kFoldUnroll], v2[kFoldUnroll];
+    __shared__ float red[4][2 * kFoldCh];
+    const int tid = threadIdx.x;
+    const int c0 = blockIdx.x * kFoldCh;
+    f32x4 a1 = {0.f, 0.f, 0.f, 0.f}, a2 = a1;
+    for (int b0 = tid; b0 < nblk; b0 += 256 * kFoldUnroll) {
+        f32x4 v1[kFoldUnroll], v2[kFoldUnroll];
 #pragma unroll
-            for (int u = 0; u < kFoldUnroll; ++u) {
-                const int b = b0 + u * kFoldSlices;
-                const bool ok = b < nblk;
-                const long off = (long)(ok ? b : b0) * 2 * C + c;
-                const float x1 = partial[off], x2 = partial[off + C];
-                v1[u] = ok ? x1 : 0.0f;
-                v2[u] = ok ? x2 : 0.0f;
-            }
-            a1 += ((v1[0] + v1[1]) + (v1[2] + v1[3])) + ((v1[4] + v1[5]) + (v1[6] + v1[7]));
-            a2 += ((v2[0] + v2[1]) + (v2[2] + v2[3])) + ((v2[4] + v2[5]) + (v2[6] + v2[7]));
+        for (int u = 0; u < kFoldUnroll; ++u) {
+            const int b = b0 + u * 256;
+            const bool ok = b < nblk;
+            const float* row = partial + (long)(ok ? b : b0) * 2 * C + c0;
+            const f32x4 x1 = *reinterpret_cast<const f32x4*>(row);
+            const f32x4 x2 = *reinterpret_cast<const f32x4*>(row + C);
+            const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+            v1[u] = ok ? x1 : zero;
+            v2[u] = ok ? x2 : zero;
         }
+        a1 += ((v1[0] + v1[1]) + (v1[2] + v1[3])) + ((v1[4] + v1[5]) + (v1[6] + v1[7]));
+        a2 += ((v2[0] + v2[1]) + (v2[2] + v2[3])) + ((v2[4] + v2[5]) + (v2[6] + v2[7]));
     }
-    red[0][slice][ch] = a1;
-    red[1][slice][ch] = a2;
+    const float w[2 * kFoldCh] = {wave_butterfly_sum(a1.x), wave_butterfly_sum(a1.y),
+                                  wave_butterfly_sum(a1.z), wave_butterfly_sum(a1.w),
+                                  wave_butterfly_sum(a2.x), wave_butterfly_sum(a2.y),
+                                  wave_butterfly_sum(a2.z), wave_butterfly_sum(a2.w)};
+    if ((tid & 63) == 0) {
+#pragma unroll
+        for (int i = 0; i < 2 * kFoldCh; ++i) red[tid >> 6][i] = w[i];
+    }
     __syncthreads();
-    if (slice != 0 || c >= C) return -1;
-    s1 = 0.0f;
-    s2 = 0.0f;
-    for (int s = 0; s < kFoldSlices; ++s) {
-        s1 += red[0][s][ch];
-        s2 += red[1][s][ch];
-    }
-    return c;
+    if (tid >= kFoldCh) return -1;
+    s1 = (red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]);
+    s2 = (red[0][kFoldCh + tid] + red[1][kFoldCh + tid]) +
+         (red[2][kFoldCh + tid] + red[3][kFoldCh + tid]);
+    return c0 + tid;
 }
 
 struct BnFwdOut {
@@ -211,21 +221,26 @@ __global__ __launch_bounds__(256) void bn_fwd_finalize_kernel(const float* __res
                                                               float unbias, const float* gamma,
                                                               const float* beta, float eps,
                                                               float momentum, BnFwdOut o) {
+    // the per-channel parameters are requested before the fold, so they arrive with the rows
+    const int cp = blockIdx.x * kFoldCh + (threadIdx.x & (kFoldCh - 1));
+    const float ga = gamma[cp], be = beta[cp];
+    const float rm = o.running_mean ? o.running_mean[cp] : 0.0f;
+    const float rv = o.running_mean ? o.running_var[cp] : 0.0f;
     float s1, s2;
     const int c = fold_partials(partial, nblk, C, s1, s2);
-    if (c >= 0) {
+    if (c >= 0) {   // c == cp for the threads that get here
         const float mean = s1 * inv_m;
         float var = s2 * inv_m - mean * mean;
         var = fmaxf(var, 0.0f);
         const float rstd = 1.0f / sqrtf(var + eps);
-        const float sc = gamma[c] * rstd;
+        const float sc = ga * rstd;
         o.mean[c] = mean;
         o.rstd[c] = rstd;
         o.scale[c] = sc;
-        o.shift[c] = beta[c] - mean * sc;
+        o.shift[c] = be - mean * sc;
         if (o.running_mean) {
-            o.running_mean[c] = (1.0f - momentum) * o.running_mean[c] + momentum * mean;
-            o.running_var[c] = (1.0f - momentum) * o.running_var[c] + momentum * (var * unbias);
+            o.running_mean[c] = (1.0f - momentum) * rm + momentum * mean;
+            o.running_var[c] = (1.0f - momentum) * rv + momentum * (var * unbias);
         }
     }
 }
@@ -239,17 +254,20 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
                                                               float* dbeta, float* coefA,
                                                               float* coefB, float* coefC,
                                                               int frozen) {
+    // the per-channel parameters are requested before the fold, so they arrive with the rows
+    const int cp = blockIdx.x * kFoldCh + (threadIdx.x & (kFoldCh - 1));
+    const float ga = gamma[cp], mu = mean[cp], rs = rstd[cp];
     float s1, s2;
     const int c = fold_partials(partial, nblk, C, s1, s2);
-    if (c >= 0) {
-        const float dg = (s2 - mean[c] * s1) * rstd[c];
+    if (c >= 0) {   // c == cp for the threads that get here
+        const float dg = (s2 - mu * s1) * rs;
         dgamma[c] = dg;
         dbeta[c] = s1;
-        coefA[c] = gamma[c] * rstd[c];
+        coefA[c] = ga * rs;
         // frozen statistics: mean and rstd are constants of the layer, so the two terms that
         // carry the gradient through them vanish and dz = gamma * rstd * g
         coefB[c] = frozen ? 0.0f : s1 * inv_m;
-        coefC[c] = frozen ? 0.0f : dg * rstd[c] * inv_m;
+        coefC[c] = frozen ? 0.0f : dg * rs * inv_m;
     }
 }
 
@@ -669,6 +687,8 @@ extern "C" int32_t pe_bn_finalize_bf16(const void* workspace, int32_t rows, int6
                PE_E_INVALID, "pe_bn_finalize_bf16: NULL pointer or no rows");
     PE_REQUIRE((running_mean == nullptr) == (running_var == nullptr), PE_E_INVALID,
                "pe_bn_finalize_bf16: give both running buffers or neither");
+    PE_REQUIRE(aligned(workspace, 16), PE_E_INVALID,
+               "pe_bn_finalize_bf16: workspace must be 16-byte aligned");
     const BnFwdOut o{mean, rstd, scale, shift, running_mean, running_var};
     const float unbias = M > 1 ? (float)((double)M / (double)(M - 1)) : 1.0f;
     pe::launch(bn_fwd_finalize_kernel, (C + kFoldCh - 1) / kFoldCh, 256, 0, as_stream(stream), static_cast<const float*>(workspace), rows, C, (float)(1.0 / (double)M), unbias, gamma, beta,
@@ -717,7 +737,7 @@ extern "C" int32_t pe_bn_finalize_apply_bf16(const void* workspace, int32_t rows
     PE_REQUIRE((running_mean == nullptr) == (running_var == nullptr), PE_E_INVALID,
                "pe_bn_finalize_apply_bf16: give both running buffers or neither");
     PE_REQUIRE(aligned(z, 16) && aligned(y, 16) && aligned(residual, 16) && aligned(sync, 128) &&
-                   aligned(scale, 32) && aligned(shift, 32),
+                   aligned(scale, 32) && aligned(shift, 32) && aligned(workspace, 16),
                PE_E_INVALID,
                "pe_bn_finalize_apply_bf16: tensors must be 16-byte aligned, scale / shift 32-byte, "
                "sync 128-byte");
@@ -744,7 +764,8 @@ extern "C" int32_t pe_bn_stats_bf16(const void* z, int64_t M, int32_t C, const f
                "pe_bn_stats_bf16: NULL pointer");
     PE_REQUIRE((running_mean == nullptr) == (running_var == nullptr), PE_E_INVALID,
                "pe_bn_stats_bf16: give both running buffers or neither");
-    PE_REQUIRE(aligned(z, 16), PE_E_INVALID, "pe_bn_stats_bf16: z not 16-byte aligned");
+    PE_REQUIRE(aligned(z, 16) && aligned(workspace, 16), PE_E_INVALID,
+               "pe_bn_stats_bf16: z and workspace must be 16-byte aligned");
     const BnGeom g = bn_geom(M, C);
     float* partial = static_cast<float*>(workspace);
     hipStream_t st = as_stream(stream);
@@ -769,7 +790,8 @@ extern "C" int32_t pe_bn_stats_apply_bf16(const void* z, int64_t M, int32_t C,
     int32_t rc = bn_check("pe_bn_stats_apply_bf16", M, C);
     if (rc != PE_OK) return rc;
     PE_REQUIRE(z && workspace, PE_E_INVALID, "pe_bn_stats_apply_bf16: NULL pointer");
-    PE_REQUIRE(aligned(z, 16), PE_E_INVALID, "pe_bn_stats_apply_bf16: z not 16-byte aligned");
+    PE_REQUIRE(aligned(z, 16) && aligned(workspace, 16), PE_E_INVALID,
+               "pe_bn_stats_apply_bf16: z and workspace must be 16-byte aligned");
     const BnGeom g = bn_geom(M, C);
     pe::launch(bn_reduce_kernel<0>, g.nblk, 256, (size_t)g.rl * 2 * C * sizeof(float), as_stream(stream), static_cast<const uint16_t*>(z), nullptr, nullptr, nullptr, nullptr, 0.0f, M, C, g,
         static_cast<float*>(workspace));
@@ -806,7 +828,7 @@ extern "C" int32_t pe_bn_bwd_bf16(const void* da, const void* a, int32_t relu, c
     PE_REQUIRE(da && z && gamma && mean && rstd && dgamma && dbeta && dz && workspace,
                PE_E_INVALID, "pe_bn_bwd_bf16: NULL pointer");
     PE_REQUIRE(aligned(da, 16) && aligned(a, 16) && aligned(z, 16) && aligned(dz, 16) &&
-                   aligned(dmasked, 16),
+                   aligned(dmasked, 16) && aligned(workspace, 16),
                PE_E_INVALID, "pe_bn_bwd_bf16: tensors must be 16-byte aligned");
     PE_REQUIRE(relu == 1 || relu == 2, PE_E_INVALID,
                "pe_bn_bwd_bf16: relu must be 1 (ReLU) or 2 (ReLU6); it only matters when a is given");
@@ -857,8 +879,8 @@ extern "C" int32_t pe_bn_bwd_from_partials_bf16(const void* g, const void* z, in
     if (rc != PE_OK) return rc;
     PE_REQUIRE(g && z && gamma && mean && rstd && dgamma && dbeta && dz && workspace && rows > 0,
                PE_E_INVALID, "pe_bn_bwd_from_partials_bf16: NULL pointer or no rows");
-    PE_REQUIRE(aligned(g, 16) && aligned(z, 16) && aligned(dz, 16), PE_E_INVALID,
-               "pe_bn_bwd_from_partials_bf16: tensors must be 16-byte aligned");
+    PE_REQUIRE(aligned(g, 16) && aligned(z, 16) && aligned(dz, 16) && aligned(workspace, 16),
+               PE_E_INVALID, "pe_bn_bwd_from_partials_bf16: tensors must be 16-byte aligned");
     const size_t cap = (pe_bn_workspace_bytes(M, C) - 256) / ((size_t)C * sizeof(float));
     PE_REQUIRE((size_t)rows * 2 + 3 <= cap, PE_E_INVALID,
                "pe_bn_bwd_from_partials_bf16: %d rows do not fit the workspace of (M, C)", rows);

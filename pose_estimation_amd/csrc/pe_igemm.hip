@@ -839,6 +839,22 @@ int32_t igemm_launch(const IgemmParams& pin, hipStream_t st, const char* what) {
     PE_CFG_MASK(64, 64, 2, true, false, 2)
 #undef PE_CFG_MASK
     PE_REQUIRE(!p.mask_z, PE_E_UNSUPPORTED, "%s: no masked kernel for tile %dx%d", what, bm, bn);
+    // 64 output channels and many pixel tiles: 256 pixels x 64 channels, four waves along the
+    // pixels, so a wave multiplies 64 x 64 and reads a third less LDS per MFMA than the 64 x 32
+    // wave tile of the 128 x 64 workgroup: the 3x3 64 -> 64 layer at 64x48, batch 256, 103.5 ->
+    // 91.9 us (PE_IGEMM_T256: 0 = off, 3 / 4 = workgroups per CU; 4 is the default).
+    if (!force && bm == 128 && bn == 64 && p.N > 32 && wg128 >= 2048) {
+        static const char* ts = getenv("PE_IGEMM_T256");
+        const int t256 = ts ? atoi(ts) : 4;
+        if (t256 == 4) {
+            if (fast) return launch_cfg<256, 64, 4, 0, false, 4, false, 1, true>(p, maxM, st, what);
+            return launch_cfg<256, 64, 4, 0, false, 4, false, 1>(p, maxM, st, what);
+        }
+        if (t256 == 3) {
+            if (fast) return launch_cfg<256, 64, 4, 0, false, 3, false, 1, true>(p, maxM, st, what);
+            return launch_cfg<256, 64, 4, 0, false, 3, false, 1>(p, maxM, st, what);
+        }
+    }
     PE_CFG_FAST(128, 128, 2, false, false, 4)
     PE_CFG_FAST(128, 64, 2, false, false, 4)
     PE_CFG_FAST(64, 128, 2, false, false, 4)

@@ -243,12 +243,32 @@ class PoseResNet:
         return pnn.conv2d(x, self.w(c), self.scale[c.name], self.shift[c.name], residual,
                           c.stride, c.pad, c.relu if relu is None else relu, **kw)
 
-    def forward_features(self, x_s2d: torch.Tensor) -> torch.Tensor:
-        stem, blocks, deconvs, final = self.specs
+    # Depth-first front: the stem, the pool and the first `front_blocks` bottlenecks run over
+    # `front_chunk` images at a time, one chunk after the other, so that what a layer writes is
+    # still in the last-level cache when the next layer reads it (at batch 256 the tensors of
+    # layer1 are 100-400 MB each, more than the cache holds).  0 = whole batch at once.
+    front_chunk = int(os.environ.get("PE_RESNET_CHUNK", "0"))
+    front_blocks = int(os.environ.get("PE_RESNET_CHUNK_BLOCKS", "3"))
+
+    def _front_shape(self, x_s2d: torch.Tensor, nblocks: int) -> Tuple[int, int, int, int]:
+        """Shape of the activation behind the first `nblocks` bottlenecks."""
+        B, h, w, _ = x_s2d.shape
+        h, w = (h - 1) // 2 + 1, (w - 1) // 2 + 1           # 3x3 stride-2 pool, pad 1
+        for b in self.specs[1][:nblocks]:
+            if b.c2.stride == 2:
+                h, w = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+        return B, h, w, self.specs[1][nblocks - 1].c3.cout
+
+    def _front(self, x_s2d: torch.Tensor, nblocks: int, out: Optional[torch.Tensor]) -> torch.Tensor:
+        stem, blocks, _, _ = self.specs
         x = pnn.stem7x7s2(x_s2d, self.w(stem), self.scale[stem.name], self.shift[stem.name], True)
         x = pnn.maxpool3x3s2(x)
+        return self._blocks(x, blocks[:nblocks], out)
+
+    def _blocks(self, x: torch.Tensor, blocks, out: Optional[torch.Tensor]) -> torch.Tensor:
         side = self._side_stream() if self.down_stream else None
-        for b in blocks:
+        for bi, b in enumerate(blocks):
+            kw = {"out": out} if (out is not None and bi == len(blocks) - 1) else {}
             if b.down and side is not None:
                 # the projection of the skip path runs beside conv1 / conv2 (it is bound by
                 # memory traffic, conv2 by the matrix cores); both streams wait for each other,
@@ -262,7 +282,20 @@ class PoseResNet:
             else:
                 o = self._conv(b.c2, self._conv(b.c1, x))
                 idn = self._conv(b.down, x) if b.down else x
-            x = self._conv(b.c3, o, residual=idn, relu=True)
+            x = self._conv(b.c3, o, residual=idn, relu=True, **kw)
+        return x
+
+    def forward_features(self, x_s2d: torch.Tensor) -> torch.Tensor:
+        stem, blocks, deconvs, final = self.specs
+        B = x_s2d.shape[0]
+        ch, nb = self.front_chunk, min(self.front_blocks, len(blocks))
+        if ch > 0 and nb > 0 and B > ch and B % ch == 0:
+            x = torch.empty(self._front_shape(x_s2d, nb), dtype=BF16, device=x_s2d.device)
+            for i in range(0, B, ch):
+                self._front(x_s2d[i:i + ch], nb, x[i:i + ch])
+            x = self._blocks(x, blocks[nb:], None)
+        else:
+            x = self._front(x_s2d, len(blocks), None)
         for d in deconvs:
             x = pnn.deconv4x4s2(x, self.w(d), self.scale[d.name], self.shift[d.name], True)
         return x

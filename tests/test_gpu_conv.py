@@ -161,3 +161,29 @@ def test_maxpool():
     ref = to.maxpool3x3s2(x)
     got = pnn.maxpool3x3s2(x.to(BF16).cuda())
     assert torch.equal(got.float().cpu(), ref)
+
+
+# 64 output channels and at least 2048 pixel tiles of 128 select the 256-pixel x 64-channel
+# workgroup (four waves along the pixels); smaller layers never reach it.  Integer operands:
+# exact, so the comparison is bit for bit.  The last tile is part-filled (266 112 pixels).
+@pytest.mark.parametrize("K,cin,bnstats", [(3, 64, False), (1, 128, False), (3, 64, True)])
+def test_conv_256_pixel_tile_for_64_channel_layers(K, cin, bnstats):
+    B, H, W, Cout, p = 22, 126, 96, 64, K // 2
+    g = torch.Generator().manual_seed(77 + K + cin)
+    x = int_tensor((B, H, W, cin), g, -2, 2)
+    w = int_tensor((Cout, cin, K, K), g, -1, 1)
+    xg, wg = x.to(BF16).cuda(), pnn.pack_conv_weight(w).cuda()
+    if bnstats:
+        ws = pnn.bn_workspace(B * H * W, Cout, "cuda:0")
+        got, rows = pnn.conv2d_bnstats(xg, wg, ws, stride=1, pad=p)
+        assert rows == (B * H * W + 255) // 256
+        part = ws.view(torch.float32)[:rows * 2 * Cout].view(rows, 2, Cout).double().sum(0).cpu()
+    else:
+        got = pnn.conv2d(xg, wg, stride=1, pad=p)
+    for b in (0, 9, B - 1):
+        ref = to.bf16r(to.conv2d(x[b:b + 1], w, stride=1, pad=p))
+        assert torch.equal(got[b:b + 1].float().cpu(), ref)
+    if bnstats:
+        z = got.double().cpu().reshape(-1, Cout)
+        assert torch.allclose(part[0], z.sum(0), rtol=1e-6, atol=1e-3)
+        assert torch.allclose(part[1], (z * z).sum(0), rtol=1e-6, atol=1e-3)

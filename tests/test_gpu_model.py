@@ -103,3 +103,18 @@ def test_predict_is_deterministic_and_batch_independent():
     assert torch.equal(a, b)
     c = net.predict(img[1:3].contiguous())
     assert torch.equal(a[1:3], c)  # batch sharding changes nothing: inference needs no collective
+
+
+def test_depth_first_front_is_bit_identical():
+    """PE_RESNET_CHUNK: the stem, the pool and the first bottlenecks run over a few images at a
+    time; every image's result is what the whole-batch pass gives."""
+    net = pm.PoseResNet("cuda:0", layers=(2, 1, 1, 1))
+    state = pm.init_state(net.specs, seed=11)
+    pm.randomize_bn(state, seed=12)
+    net.load_state(state)
+    img = torch.from_numpy(synthetic.images_u8(6, 64, 48, seed=3)).cuda()
+    ref = net.predict(img)
+    for chunk, nblocks in ((2, 2), (3, 3), (1, 5)):
+        net.front_chunk, net.front_blocks = chunk, nblocks
+        assert torch.equal(net.predict(img), ref)
+    net.front_chunk = 0
