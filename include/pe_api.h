@@ -268,6 +268,29 @@ int32_t pe_conv2d_fwd_bf16(const pe_conv_desc* d, const void* x, const void* w,
                            const float* scale, const float* shift, const void* residual,
                            void* y, pe_stream_t stream);
 
+/* Up to three convolutions over the same pixels in one launch (inference): stage 0 is any
+ * stride-1 or strided conv pe_conv2d_fwd_bf16 takes with Cin a multiple of 64; every later stage
+ * is a 1x1 stride-1 conv whose input is the previous stage's output y (its desc.B/H/W/Cin must
+ * say so).  A workgroup computes its 256 output pixels of stage 0, then the same pixels of
+ * stage 1 from what it has just stored, and so on, so a bottleneck's conv2 -> conv3 -> next
+ * conv1 costs one launch and the intermediate tensors are read back from the cache their
+ * producer filled.  Every stage's y is written in full, bit for bit what the stage would give
+ * alone.  Each stage has its own epilogue operands (scale, shift, residual may be NULL; relu
+ * in desc).  bf16 NHWC outputs only, Cout a multiple of 8.
+ * Replaces: consecutive layer calls of the reference's network files (nets/mobilenet_v2.py,
+ * model/mobilenet_pose.py; PoseEstimation.pyproj:31-32, files absent). */
+typedef struct pe_conv_stage {
+    pe_conv_desc desc;
+    const void* w;
+    const float* scale;
+    const float* shift;
+    const void* residual;
+    void* y;
+} pe_conv_stage;
+
+int32_t pe_conv2d_fwd_chain_bf16(const void* x, const pe_conv_stage* stages, int32_t nstage,
+                                 pe_stream_t stream);
+
 /* ConvTranspose 4x4, stride 2, pad 1: x [B,H,W,Cin] -> y [B,2H,2W,Cout], four parity phases. */
 int32_t pe_deconv4x4s2_fwd_bf16(int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout,
                                 int32_t relu, const void* x, const void* w_phases,

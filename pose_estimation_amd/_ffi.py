@@ -89,6 +89,7 @@ SIGNATURES = {
         c_int32,
         [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p],
     ),
+    "pe_conv2d_fwd_chain_bf16": (c_int32, [c_void_p, c_void_p, c_int32, c_void_p]),
     "pe_deconv4x4s2_fwd_bf16": (
         c_int32,
         [c_int32, c_int32, c_int32, c_int32, c_int32, c_int32, c_void_p, c_void_p, c_void_p,
@@ -254,6 +255,14 @@ class ConvDesc(ctypes.Structure):
                                        "relu", "out_f32_nchw")]
 
 
+class ConvStage(ctypes.Structure):
+    """Mirror of pe_conv_stage (include/pe_api.h)."""
+
+    _fields_ = [("desc", ConvDesc), ("w", c_void_p), ("scale", c_void_p), ("shift", c_void_p),
+                ("residual", c_void_p), ("y", c_void_p)]
+
+
+PE_CONV_MAX_CHAIN = 3
 PE_WGRAD_MAX_BATCH = 8
 
 

@@ -131,9 +131,10 @@ static int32_t attach_stats(IgemmParams& p, const StatReq* sr, const char* what)
 
 using namespace pe;
 
-static int32_t conv2d_fwd_impl(const pe_conv_desc* d, const void* x, const void* w,
-                               const float* scale, const float* shift, const void* residual,
-                               void* y, const StatReq* sr, pe_stream_t stream) {
+// The engine parameters of one forward convolution (no statistics attached).
+static int32_t conv2d_fwd_params(const pe_conv_desc* d, const void* x, const void* w,
+                                 const float* scale, const float* shift, const void* residual,
+                                 void* y, IgemmParams& p) {
     PE_REQUIRE(d != nullptr, PE_E_INVALID, "pe_conv2d_fwd_bf16: NULL descriptor");
     PE_REQUIRE(d->KH > 0 && d->KW > 0 && d->KH * d->KW <= kMaxTaps, PE_E_UNSUPPORTED,
                "pe_conv2d_fwd_bf16: filter %dx%d not supported", d->KH, d->KW);
@@ -145,7 +146,6 @@ static int32_t conv2d_fwd_impl(const pe_conv_desc* d, const void* x, const void*
     PE_REQUIRE(Ho > 0 && Wo > 0, PE_E_INVALID, "pe_conv2d_fwd_bf16: empty output");
     PE_REQUIRE(!(d->out_f32_nchw && residual), PE_E_UNSUPPORTED,
                "pe_conv2d_fwd_bf16: residual with float32 NCHW output is not supported");
-    IgemmParams p;
     base_params(p);
     p.x = static_cast<const uint16_t*>(x);
     p.w = static_cast<const uint16_t*>(w);
@@ -193,9 +193,36 @@ static int32_t conv2d_fwd_impl(const pe_conv_desc* d, const void* x, const void*
     p.ldc = d->Cout;
     p.relu = d->relu;
     p.out_mode = d->out_f32_nchw ? 1 : 0;
-    const int32_t rc = attach_stats(p, sr, "pe_conv2d_fwd_bf16");
+    return PE_OK;
+}
+
+static int32_t conv2d_fwd_impl(const pe_conv_desc* d, const void* x, const void* w,
+                               const float* scale, const float* shift, const void* residual,
+                               void* y, const StatReq* sr, pe_stream_t stream) {
+    IgemmParams p;
+    int32_t rc = conv2d_fwd_params(d, x, w, scale, shift, residual, y, p);
+    if (rc != PE_OK) return rc;
+    rc = attach_stats(p, sr, "pe_conv2d_fwd_bf16");
     if (rc != PE_OK) return rc;
     return igemm_launch(p, as_stream(stream), "pe_conv2d_fwd_bf16");
+}
+
+extern "C" int32_t pe_conv2d_fwd_chain_bf16(const void* x, const pe_conv_stage* stages,
+                                            int32_t nstage, pe_stream_t stream) {
+    PE_REQUIRE(x != nullptr && stages != nullptr && nstage >= 1 && nstage <= kMaxChain,
+               PE_E_INVALID, "pe_conv2d_fwd_chain_bf16: 1 to %d stages", kMaxChain);
+    IgemmParams p[kMaxChain];
+    const void* in = x;
+    for (int s = 0; s < nstage; ++s) {
+        const pe_conv_stage& g = stages[s];
+        PE_REQUIRE(g.w != nullptr && g.y != nullptr, PE_E_INVALID,
+                   "pe_conv2d_fwd_chain_bf16: stage %d: NULL pointer", s);
+        const int32_t rc = conv2d_fwd_params(&g.desc, in, g.w, g.scale, g.shift, g.residual, g.y,
+                                             p[s]);
+        if (rc != PE_OK) return rc;
+        in = g.y;
+    }
+    return igemm_chain_launch(p, nstage, as_stream(stream), "pe_conv2d_fwd_chain_bf16");
 }
 
 extern "C" int32_t pe_conv2d_fwd_bf16(const pe_conv_desc* d, const void* x, const void* w,

@@ -87,4 +87,13 @@ inline void igemm_defaults(IgemmParams& p) {
 // Launches the engine (asynchronous).  Returns PE_OK / PE_E_*.
 int32_t igemm_launch(const IgemmParams& p, hipStream_t st, const char* what);
 
+// Up to kMaxChain layers over the same pixel tiles in one launch: stage s > 0 is a 1x1 stride-1
+// layer whose input is the output of stage s - 1 (see igemm_chain_kernel).
+constexpr int kMaxChain = 3;
+struct IgemmChainArgs {
+    IgemmParams st[kMaxChain];
+    int nstage;
+};
+int32_t igemm_chain_launch(const IgemmParams* stages, int nstage, hipStream_t st, const char* what);
+
 }  // namespace pe

@@ -71,11 +71,18 @@ __device__ __forceinline__ void wait_vmcnt() {
 // chain: every tile row keeps the pointer of its centre pixel and one bit per tap ("this tap
 // lies inside the image"), and a K step adds a wave-uniform byte offset.  Needs single-pixel K
 // runs, Cin a multiple of 64 and at most 32 taps per phase (igemm_launch checks).
-template <int BM, int BN, int WM, int PIPE, bool PF, int MINB, bool MASK = false, int WN = 2,
-          bool FAST = false, bool RES = false>
-__global__ __launch_bounds__(WM * WN * 64, MINB)
-__attribute__((amdgpu_waves_per_eu(MINB * WM * WN / 4, MINB * WM * WN / 4))) void igemm_kernel(const IgemmParams p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
+// XCD-aware tile order: workgroups that share an XCD (ids congruent mod 8) take a contiguous
+// run of tiles, so the n-tiles of one pixel panel reuse that XCD's L2.
+__device__ __forceinline__ int xcd_tile_order(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7;
+    const int xcd = bid & 7, loc = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+}
+
+// One output tile: tile `bid` (in pixel-panel-major order, n-tiles of a panel adjacent) of
+// phase `ph`, computed by the whole workgroup in the LDS at `smem`.
+template <int BM, int BN, int WM, int PIPE, bool PF, bool MASK, int WN, bool FAST, bool RES>
+__device__ __forceinline__ void igemm_tile(const IgemmParams& p, char* smem, int bid, const int ph) {
     constexpr bool DB = PIPE == 1;    // the double buffer with draining barriers
     constexpr int NS = PIPE >= 2 ? PIPE : 0;   // ring stages
     constexpr int NT = WM * WN * 64;  // threads
@@ -99,7 +106,6 @@ __attribute__((amdgpu_waves_per_eu(MINB * WM * WN / 4, MINB * WM * WN / 4))) voi
     const int wave_n = wid % WN;
 
     // ---- phase (uniform)
-    const int ph = blockIdx.y;
     const int Ho = p.ph_Ho[ph], Wo = p.ph_Wo[ph];
     const int T = p.ph_T[ph];
     const int t0 = p.ph_t0[ph];
@@ -111,15 +117,6 @@ __attribute__((amdgpu_waves_per_eu(MINB * WM * WN / 4, MINB * WM * WN / 4))) voi
     const int ntn = (p.N + BN - 1) / BN;
     const long ntiles = ((M + BM - 1) / BM) * ntn;
 
-    // XCD-aware tile order: workgroups that share an XCD (ids congruent mod 8) take a
-    // contiguous run of tiles, so the n-tiles of one pixel panel reuse that XCD's L2.
-    int bid = blockIdx.x;
-    {
-        const int nwg = gridDim.x;
-        const int q = nwg >> 3, r = nwg & 7;
-        const int xcd = bid & 7, loc = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
-    }
     if (bid >= ntiles) return;  // uniform: phases may have fewer tiles than the grid
     const int tile_m = bid / ntn;
     const int tile_n = bid - tile_m * ntn;
@@ -632,6 +629,15 @@ __attribute__((amdgpu_waves_per_eu(MINB * WM * WN / 4, MINB * WM * WN / 4))) voi
     }
 }
 
+template <int BM, int BN, int WM, int PIPE, bool PF, int MINB, bool MASK = false, int WN = 2,
+          bool FAST = false, bool RES = false>
+__global__ __launch_bounds__(WM * WN * 64, MINB)
+__attribute__((amdgpu_waves_per_eu(MINB * WM * WN / 4, MINB * WM * WN / 4))) void igemm_kernel(const IgemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    igemm_tile<BM, BN, WM, PIPE, PF, MASK, WN, FAST, RES>(
+        p, smem, xcd_tile_order(blockIdx.x, gridDim.x), blockIdx.y);
+}
+
 template <int BM, int BN, int PIPE, int NT = 256, bool MASK = false>
 static constexpr size_t lds_bytes() {
     const size_t ktile = (size_t)(BM + BN) * ROWB * (PIPE == 0 ? 1 : (PIPE == 1 ? 2 : PIPE));
@@ -668,8 +674,9 @@ static int32_t launch_cfg(IgemmParams& p, long maxM, hipStream_t st, const char*
     return check_launch(what);
 }
 
-int32_t igemm_launch(const IgemmParams& pin, hipStream_t st, const char* what) {
-    IgemmParams p = pin;
+// Fills in the derived fields of a launch (single phase, packed tap words, non-temporal choice)
+// and checks what every kernel of the family assumes.  maxM: GEMM rows of the largest phase.
+static int32_t igemm_prepare(IgemmParams& p, long& maxM, const char* what) {
     if (p.wk_row == 0) p.wk_row = p.T * p.Cin;
     if (p.nphase <= 0) {  // single phase described by the scalar fields
         p.nphase = 1;
@@ -701,7 +708,7 @@ int32_t igemm_launch(const IgemmParams& pin, hipStream_t st, const char* what) {
                PE_E_INVALID, "%s: tensors must be 16-byte aligned", what);
     PE_REQUIRE(p.out_mode == 1 || p.ldc % 4 == 0, PE_E_UNSUPPORTED,
                "%s: output channel pitch must be a multiple of 4", what);
-    long maxM = 0;
+    maxM = 0;
     for (int i = 0; i < p.nphase; ++i) {
         PE_REQUIRE(p.ph_Ho[i] > 0 && p.ph_Wo[i] > 0 && p.ph_T[i] >= 1 &&
                        p.ph_t0[i] + p.ph_T[i] <= kMaxTaps,
@@ -744,6 +751,23 @@ int32_t igemm_launch(const IgemmParams& pin, hipStream_t st, const char* what) {
         const long thr = nts ? atol(nts) : 64;
         p.nt_store = thr > 0 && (long)p.B * p.OH * p.OW * p.ldc * 2 >= thr * 1000000L;
     }
+    return PE_OK;
+}
+
+// cheap staging addresses are possible (see the kernel's FAST parameter)
+static bool igemm_fast_ok(const IgemmParams& p) {
+    bool fast = p.cshift == 31 && p.Cin % BK == 0;
+    for (int i = 0; i < p.nphase; ++i) fast = fast && p.ph_T[i] <= 32;
+    return fast;
+}
+
+int32_t igemm_launch(const IgemmParams& pin, hipStream_t st, const char* what) {
+    IgemmParams p = pin;
+    long maxM = 0;
+    {
+        const int32_t rc = igemm_prepare(p, maxM, what);
+        if (rc != PE_OK) return rc;
+    }
     // tile choice: 128-pixel tiles unless they leave the chip under-filled; when even 64-pixel
     // tiles give fewer than two workgroups per CU, 64 x 64 tiles with the double-buffered
     // pipeline (each workgroup hides its own load latency) measured 15-25 % faster
@@ -758,8 +782,7 @@ int32_t igemm_launch(const IgemmParams& pin, hipStream_t st, const char* what) {
         minb = 2;
     }
     // cheap addressing where the layer allows it (PE_IGEMM_FAST=0: off, for comparison)
-    bool fast = p.cshift == 31 && p.Cin % BK == 0;
-    for (int i = 0; i < p.nphase; ++i) fast = fast && p.ph_T[i] <= 32;
+    bool fast = igemm_fast_ok(p);
     {
         static const char* fs = getenv("PE_IGEMM_FAST");
         if (fs && atoi(fs) == 0) fast = false;
@@ -839,11 +862,12 @@ int32_t igemm_launch(const IgemmParams& pin, hipStream_t st, const char* what) {
     PE_CFG_MASK(64, 64, 2, true, false, 2)
 #undef PE_CFG_MASK
     PE_REQUIRE(!p.mask_z, PE_E_UNSUPPORTED, "%s: no masked kernel for tile %dx%d", what, bm, bn);
-    // 64 output channels and many pixel tiles: 256 pixels x 64 channels, four waves along the
+    // 64 output channels and 1024 or more 128-pixel tiles: 256 pixels x 64 channels, four waves along the
     // pixels, so a wave multiplies 64 x 64 and reads a third less LDS per MFMA than the 64 x 32
     // wave tile of the 128 x 64 workgroup: the 3x3 64 -> 64 layer at 64x48, batch 256, 103.5 ->
     // 91.9 us (PE_IGEMM_T256: 0 = off, 3 / 4 = workgroups per CU; 4 is the default).
-    if (!force && bm == 128 && bn == 64 && p.N > 32 && wg128 >= 2048) {
+    static const char* t256min = getenv("PE_IGEMM_T256_MIN");   // tuning aid: least 128-pixel tiles
+    if (!force && bm == 128 && bn == 64 && p.N > 32 && wg128 >= (t256min ? atol(t256min) : 1024)) {
         static const char* ts = getenv("PE_IGEMM_T256");
         const int t256 = ts ? atoi(ts) : 4;
         if (t256 == 4) {
@@ -873,6 +897,70 @@ int32_t igemm_launch(const IgemmParams& pin, hipStream_t st, const char* what) {
 #undef PE_CFG_FAST
 #undef PE_CFG
     PE_REQUIRE(false, PE_E_UNSUPPORTED, "%s: no kernel for tile %dx%d wm %d db %d pf %d minb %d", what, bm, bn, wm, db, pf, minb);
+    return check_launch(what);
+}
+
+// ---- chained launches ------------------------------------------------------------------------
+// Several convolutions over the SAME pixel tiles in one launch: a workgroup computes its 256
+// pixels of stage 0 (all n-tiles, one after the other), then the same pixels of stage 1, whose
+// input is what it has just stored, and so on.  Stages after the first are therefore 1x1
+// stride-1 layers reading the previous stage's output: a pixel's inputs were all written by the
+// same workgroup, whose stores have reached the L2 (vmcnt drained, workgroup barrier) before its
+// next stage loads them.  What it buys: one launch instead of up to three, the matrix-core-
+// bound stage of one workgroup runs beside the bandwidth-bound stage of its neighbours on the
+// CU, and a stage's input comes from the cache that its producer just filled.
+__global__ __launch_bounds__(256, 3)
+__attribute__((amdgpu_waves_per_eu(3, 3))) void igemm_chain_kernel(const IgemmChainArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tile_m = xcd_tile_order(blockIdx.x, gridDim.x);
+    for (int s = 0; s < a.nstage; ++s) {
+        const IgemmParams& p = a.st[s];
+        const int ntn = (p.N + 63) / 64;
+        for (int j = 0; j < ntn; ++j) {
+            igemm_tile<256, 64, 4, 0, false, false, 1, true, false>(p, smem, tile_m * ntn + j, 0);
+            // the tile's stores are in the L2 and every wave is done with the LDS
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+    }
+}
+
+int32_t igemm_chain_launch(const IgemmParams* stages, int nstage, hipStream_t st, const char* what) {
+    PE_REQUIRE(stages != nullptr && nstage >= 1 && nstage <= kMaxChain, PE_E_INVALID,
+               "%s: 1 to %d stages", what, kMaxChain);
+    IgemmChainArgs a;
+    a.nstage = nstage;
+    long M = 0;
+    for (int s = 0; s < nstage; ++s) {
+        IgemmParams& p = a.st[s];
+        p = stages[s];
+        long maxM = 0;
+        const int32_t rc = igemm_prepare(p, maxM, what);
+        if (rc != PE_OK) return rc;
+        PE_REQUIRE(p.nphase == 1 && p.out_mode == 0 && (p.N & 7) == 0 && (p.ldc & 7) == 0 &&
+                       !p.stat_partial && !p.mask_z && igemm_fast_ok(p),
+                   PE_E_UNSUPPORTED,
+                   "%s: stage %d must be a single-phase bf16 NHWC layer with channel counts that "
+                   "are multiples of 64 in and 8 out", what, s);
+        if (s == 0) {
+            M = maxM;
+        } else {
+            const IgemmParams& q = a.st[s - 1];
+            PE_REQUIRE(maxM == M && p.T == 1 && p.tap_dy[0] == 0 && p.tap_dx[0] == 0 &&
+                           p.sy == 1 && p.sx == 1 && p.Hi == q.OH && p.Wi == q.OW &&
+                           p.Cx == q.ldc && p.Cin == q.N &&
+                           p.x == static_cast<const uint16_t*>(q.y),
+                       PE_E_INVALID,
+                       "%s: stage %d must be a 1x1 stride-1 layer over the output of stage %d",
+                       what, s, s - 1);
+            a.st[s - 1].nt_store = 0;   // read again by this stage: keep it in the cache
+        }
+        PE_REQUIRE(p.osy == 1 && p.osx == 1 && p.ph_ooy[0] == 0 && p.ph_oox[0] == 0 &&
+                       p.OH == p.ph_Ho[0] && p.OW == p.ph_Wo[0],
+                   PE_E_UNSUPPORTED, "%s: stage %d scatters its output", what, s);
+    }
+    constexpr size_t lds = lds_bytes<256, 64, 0, 256, false>();
+    pe::launch(igemm_chain_kernel, (unsigned)((M + 255) / 256), 256, lds, st, a);
     return check_launch(what);
 }
 

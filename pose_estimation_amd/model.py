@@ -265,9 +265,51 @@ class PoseResNet:
         x = pnn.maxpool3x3s2(x)
         return self._blocks(x, blocks[:nblocks], out)
 
+    # Chained bottlenecks (PE_RESNET_CHAIN=1): in the stages whose 3x3 conv has 64 output
+    # channels (layer1), conv2 -> conv3 -> the next block's conv1 run as ONE launch over the same
+    # pixel tiles (pe_conv2d_fwd_chain_bf16).  Bit-identical, and measured slower than a launch
+    # per conv at batch 256 (389 against 375 us per bottleneck tail, 5.21 against 5.07 ms per
+    # forward): 96 resident workgroups per XCD write 12 MB between a tile's store and its
+    # re-read, three times the L2, so the re-read is served from memory as before, and the
+    # 64-channel sub-tiles of the chain store 128-byte runs.  Off by default.
+    chain = os.environ.get("PE_RESNET_CHAIN", "0") == "1"
+
+    def _stage(self, c: ConvSpec, residual=None, relu=None, out=None) -> dict:
+        return {"w": self.w(c), "scale": self.scale[c.name], "shift": self.shift[c.name],
+                "residual": residual, "stride": c.stride, "pad": c.pad,
+                "relu": c.relu if relu is None else relu, "out": out}
+
+    def _chainable(self, b: BlockSpec) -> bool:
+        return self.chain and b.c2.cout == 64 and b.c2.cin == 64 and b.c2.stride == 1
+
     def _blocks(self, x: torch.Tensor, blocks, out: Optional[torch.Tensor]) -> torch.Tensor:
         side = self._side_stream() if self.down_stream else None
+        c1_out = None   # conv1 of the current block, when the previous block's chain made it
         for bi, b in enumerate(blocks):
+            last = bi == len(blocks) - 1
+            if self._chainable(b):
+                main = torch.cuda.current_stream(self.device)
+                if b.down and side is not None:
+                    side.wait_stream(main)
+                    with torch.cuda.stream(side):
+                        idn = self._conv(b.down, x)
+                elif b.down:
+                    idn = self._conv(b.down, x)
+                else:
+                    idn = x
+                o1 = c1_out if c1_out is not None else self._conv(b.c1, x)
+                if b.down and side is not None:
+                    main.wait_stream(side)
+                nxt = blocks[bi + 1] if not last else None
+                stages = [self._stage(b.c2),
+                          self._stage(b.c3, residual=idn, relu=True, out=out if last else None)]
+                if nxt is not None and nxt.c1.stride == 1 and nxt.c1.k == 1:
+                    stages.append(self._stage(nxt.c1))
+                outs = pnn.conv2d_chain(o1, stages)
+                x = outs[1]
+                c1_out = outs[2] if len(outs) == 3 else None
+                continue
+            have_c1, c1_out = c1_out, None
             kw = {"out": out} if (out is not None and bi == len(blocks) - 1) else {}
             if b.down and side is not None:
                 # the projection of the skip path runs beside conv1 / conv2 (it is bound by
@@ -277,10 +319,10 @@ class PoseResNet:
                 side.wait_stream(main)
                 with torch.cuda.stream(side):
                     idn = self._conv(b.down, x)
-                o = self._conv(b.c2, self._conv(b.c1, x))
+                o = self._conv(b.c2, have_c1 if have_c1 is not None else self._conv(b.c1, x))
                 main.wait_stream(side)
             else:
-                o = self._conv(b.c2, self._conv(b.c1, x))
+                o = self._conv(b.c2, have_c1 if have_c1 is not None else self._conv(b.c1, x))
                 idn = self._conv(b.down, x) if b.down else x
             x = self._conv(b.c3, o, residual=idn, relu=True, **kw)
         return x

@@ -14,7 +14,8 @@ from typing import Optional
 import numpy as np
 import torch
 
-from ._ffi import PE_WGRAD_MAX_BATCH, ConvDesc, WgradJob, check, lib
+from ._ffi import (PE_CONV_MAX_CHAIN, PE_WGRAD_MAX_BATCH, ConvDesc, ConvStage, WgradJob, check,
+                   lib)
 from .ops import _need_gpu, _ptr, _stream, on_device
 
 BF16 = torch.bfloat16
@@ -125,6 +126,47 @@ def conv2d(x: torch.Tensor, w: torch.Tensor, scale: Optional[torch.Tensor] = Non
         check(lib().pe_conv2d_fwd_bf16(ctypes.addressof(d), x.data_ptr(), w.data_ptr(), _ptr(scale),
                                        _ptr(shift), _ptr(residual), out.data_ptr(), _stream(x)))
     return out
+
+
+def conv2d_chain(x: torch.Tensor, stages) -> list:
+    """Up to three convolutions over the same pixels in one launch (pe_conv2d_fwd_chain_bf16).
+
+    stages: dicts with w [Cout,KH,KW,Cin] and optionally scale, shift, residual, stride, pad,
+    relu, out; every stage after the first must be a 1x1 stride-1 conv over the previous
+    stage's output.  Returns the list of outputs, each what conv2d would give for that stage."""
+    _check_act(x)
+    if not 1 <= len(stages) <= PE_CONV_MAX_CHAIN:
+        raise ValueError(f"1 to {PE_CONV_MAX_CHAIN} stages")
+    arr = (ConvStage * len(stages))()
+    outs, keep = [], []
+    B, H, W, Cin = x.shape
+    for i, st in enumerate(stages):
+        w = st["w"]
+        scale, shift, residual = st.get("scale"), st.get("shift"), st.get("residual")
+        stride, pad, relu = int(st.get("stride", 1)), int(st.get("pad", 0)), bool(st.get("relu", False))
+        _need_gpu(w, scale, shift, residual, st.get("out"))
+        Cout, KH, KW, Cin2 = w.shape
+        if Cin2 != Cin or w.dtype != BF16 or not w.is_contiguous():
+            raise ValueError(f"stage {i}: w must be contiguous bfloat16 [Cout,KH,KW,{Cin}]")
+        Ho = (H + 2 * pad - KH) // stride + 1
+        Wo = (W + 2 * pad - KW) // stride + 1
+        out = st.get("out")
+        if out is None:
+            out = torch.empty((B, Ho, Wo, Cout), dtype=BF16, device=x.device)
+        elif tuple(out.shape) != (B, Ho, Wo, Cout) or out.dtype != BF16 or not out.is_contiguous():
+            raise ValueError(f"stage {i}: out must be contiguous bfloat16 {(B, Ho, Wo, Cout)}")
+        if residual is not None and (residual.shape != out.shape or residual.dtype != BF16):
+            raise ValueError(f"stage {i}: residual must match the output")
+        arr[i].desc = ConvDesc(B, H, W, Cin, Cout, KH, KW, stride, pad, int(relu), 0)
+        arr[i].w, arr[i].scale, arr[i].shift = w.data_ptr(), _ptr(scale), _ptr(shift)
+        arr[i].residual, arr[i].y = _ptr(residual), out.data_ptr()
+        keep += [w, scale, shift, residual]
+        outs.append(out)
+        H, W, Cin = Ho, Wo, Cout
+    with on_device(x):
+        check(lib().pe_conv2d_fwd_chain_bf16(x.data_ptr(), ctypes.addressof(arr), len(stages),
+                                             _stream(x)))
+    return outs
 
 
 def fuse_upsample_add(base: Optional[torch.Tensor], lows, log2_factors, relu: bool = True,

@@ -187,3 +187,43 @@ def test_conv_256_pixel_tile_for_64_channel_layers(K, cin, bnstats):
         z = got.double().cpu().reshape(-1, Cout)
         assert torch.allclose(part[0], z.sum(0), rtol=1e-6, atol=1e-3)
         assert torch.allclose(part[1], (z * z).sum(0), rtol=1e-6, atol=1e-3)
+
+
+# pe_conv2d_fwd_chain_bf16: conv2 (3x3) -> conv3 (1x1 + residual + ReLU) -> next conv1 (1x1) of a
+# bottleneck in one launch over the same pixel tiles.  Every stage's output must be, bit for
+# bit, what the stage gives as a launch of its own; the first stage is also held against the
+# oracle.  2 x 37 x 29 pixels: the last 256-pixel tile is part-filled.
+@pytest.mark.parametrize("nstage,c_last", [(3, 64), (3, 128), (2, 0), (1, 0)])
+def test_conv_chain_equals_separate_launches(nstage, c_last):
+    B, H, W = 2, 37, 29
+    g = torch.Generator().manual_seed(5 + nstage + c_last)
+    x = rand_bf16((B, H, W, 64), g).to(BF16).cuda()
+    chans = [(64, 64, 3), (64, 256, 1), (256, c_last, 1)][:nstage]
+    stages, ws = [], []
+    for (ci, co, k) in chans:
+        wf = rand_bf16((co, ci, k, k), g, (2.0 / (ci * k * k)) ** 0.5)
+        ws.append(wf)
+        stages.append({"w": pnn.pack_conv_weight(wf).cuda(),
+                       "scale": (torch.rand(co, generator=g) + 0.5).cuda(),
+                       "shift": (torch.randn(co, generator=g) * 0.1).cuda(),
+                       "pad": k // 2, "relu": True})
+    if nstage >= 2:
+        stages[1]["residual"] = rand_bf16((B, H, W, 256), g).to(BF16).cuda()
+    outs = pnn.conv2d_chain(x, stages)
+    cur = x
+    for st, got in zip(stages, outs):
+        want = pnn.conv2d(cur, st["w"], st["scale"], st["shift"], st.get("residual"), 1,
+                          st["pad"], True)
+        assert torch.equal(got, want)
+        cur = want
+    ref = to.conv2d(x.float().cpu(), ws[0], stages[0]["scale"].cpu(), stages[0]["shift"].cpu(),
+                    None, 1, 1, relu=True)
+    close(outs[0], ref)
+
+
+def test_conv_chain_rejects_a_stage_that_is_not_pointwise():
+    g = torch.Generator().manual_seed(9)
+    x = rand_bf16((1, 8, 8, 64), g).to(BF16).cuda()
+    w3 = pnn.pack_conv_weight(rand_bf16((64, 64, 3, 3), g)).cuda()
+    with pytest.raises(RuntimeError):
+        pnn.conv2d_chain(x, [{"w": w3, "pad": 1}, {"w": w3, "pad": 1}])

@@ -118,3 +118,19 @@ def test_depth_first_front_is_bit_identical():
         net.front_chunk, net.front_blocks = chunk, nblocks
         assert torch.equal(net.predict(img), ref)
     net.front_chunk = 0
+
+
+def test_chained_bottlenecks_are_bit_identical():
+    """PE_RESNET_CHAIN: conv2 -> conv3 -> next conv1 of the 64-channel bottlenecks in one launch."""
+    net = pm.PoseResNet("cuda:0", layers=(3, 1, 1, 1))
+    state = pm.init_state(net.specs, seed=13)
+    pm.randomize_bn(state, seed=14)
+    net.load_state(state)
+    img = torch.from_numpy(synthetic.images_u8(3, 64, 48, seed=4)).cuda()
+    net.chain = False
+    ref = net.predict(img)
+    net.chain = True
+    assert torch.equal(net.predict(img), ref)
+    net.front_chunk, net.front_blocks = 1, 2     # the chain's last block writes into the slice
+    assert torch.equal(net.predict(img), ref)
+    net.chain, net.front_chunk = False, 0
