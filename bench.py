@@ -501,6 +501,12 @@ class Train(Workload):
         self.net.train_step(self.imgs, self.joints, self.mask, lr=1e-3,
                             host_replay=self.host_replay)
 
+    def dp_check(self, dist, on_host):
+        """After the timed steps of an N > 1 run: every rank trained on its own images, so the
+        ranks hold identical parameters only if every bucket of every step was summed over all
+        of them.  Two checksums of the float32 master arena, MAX and MIN over the ranks."""
+        return _arena_identical_across_ranks(self.net.master, dist, on_host)
+
     def roofline(self, kern_ms):
         ach = self.flops_per_step / (kern_ms * 1e-3) / 1e12
         return {"bound": "mfma", "kernel": self.kernel, "achieved": ach, "peak": self.peak,
@@ -580,6 +586,9 @@ class HRNetTrain(Workload):
                 "unit": "TFLOP/s", "frac": ach / self.peak,
                 "flops_per_step": self.flops_per_step, "step_ms": kern_ms, "traffic": None}
 
+    def dp_check(self, dist, on_host):
+        return _arena_identical_across_ranks(self.net.master, dist, on_host)
+
     def cpu_baseline(self):
         import oracle
         from oracle import torch_oracle as to
@@ -647,6 +656,9 @@ class MobileNetTrain(Workload):
                 "unit": "TFLOP/s", "frac": ach / self.peak,
                 "flops_per_step": self.flops_per_step, "step_ms": kern_ms, "traffic": None}
 
+    def dp_check(self, dist, on_host):
+        return _arena_identical_across_ranks(self.net.master, dist, on_host)
+
     def cpu_baseline(self):
         from oracle import torch_oracle as to
         from pose_estimation_amd import mobilenet as mb
@@ -700,6 +712,9 @@ class MobileNetDetTrain(MobileNetTrain):
         self.net.train_step(self.imgs, self.joints, None, lr=1e-3,
                             det_labels=(classes, weights, regs))
 
+    def dp_check(self, dist, on_host):
+        return _arena_identical_across_ranks(self.net.master, dist, on_host)
+
     def cpu_baseline(self):
         from oracle import torch_oracle as to
         from pose_estimation_amd import mobilenet as mb
@@ -721,6 +736,19 @@ class MobileNetDetTrain(MobileNetTrain):
                 "kind": "port",
                 "sample": f"torch-CPU autograd oracle (forward + backward from given head "
                           f"gradients, no loss, no optimizer), batch {B}, one run ({dt:.1f} s)"}
+
+
+def _arena_identical_across_ranks(arena, dist, on_host):
+    a = arena.detach().double()
+    chk = torch.stack([a.sum(), a.abs().sum(), (a * a).sum()])
+    if on_host:
+        chk = chk.cpu()
+    hi, lo = chk.clone(), chk.clone()
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    finite = bool(torch.isfinite(hi).all())
+    return {"params_identical_across_ranks": finite and bool((hi == lo).all()),
+            "ranks": dist.get_world_size(), "checksum": float(hi[1])}
 
 
 WORKLOADS = {"decode": Decode, "render": Render, "mse": Mse, "mse_fused": MseFused, "adam": Adam,
@@ -890,6 +918,10 @@ def main() -> None:
                        "sharding": getattr(wl, "sharding", "batch, no collective")},
             "roofline": roofline_of(wl, dev_ms / args.steps),
         }
+    if dist is not None and hasattr(wl, "dp_check"):
+        chk = wl.dp_check(dist, rehearse)       # a collective: every rank takes part
+        if out is not None:
+            out["dp_check"] = chk
 
     # The metric also names network inference and the data-parallel training step.  A default
     # run measures them after the headline workload, with the same barrier-bracketed loop, and
@@ -935,6 +967,8 @@ def main() -> None:
                                         "sharding": getattr(w2, "sharding",
                                                             "batch, no collective")},
                              "roofline": roofline_of(w2, d2 / steps2)}
+                if dist is not None and hasattr(w2, "dp_check"):
+                    also[key]["dp_check"] = w2.dp_check(dist, rehearse)
                 legs.append((key, w2))
             except Exception as exc:  # noqa: BLE001 - recorded in the line, headline kept
                 also[key] = {"error": f"{type(exc).__name__}: {exc}"[:300]}

@@ -141,3 +141,48 @@ def test_bench_refuses_more_ranks_than_gpus():
     r = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "8"], env=env,
                        capture_output=True, text=True, timeout=120)
     assert r.returncode == 2 and "--gpus 8" in r.stderr and "{" not in r.stdout
+
+
+def _identity_worker(rank, world, port, q):
+    import importlib.util
+    from pathlib import Path
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        spec = importlib.util.spec_from_file_location(
+            "bench", Path(__file__).resolve().parent.parent / "bench.py")
+        bench = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(bench)
+        same = torch.linspace(-1.0, 1.0, 1000)
+        a = bench._arena_identical_across_ranks(same, dist, True)
+        differs = same.clone()
+        differs[17] += 1e-3 * rank          # one element, one rank
+        b = bench._arena_identical_across_ranks(differs, dist, True)
+        broken = same.clone()
+        broken[3] = float("nan")
+        c = bench._arena_identical_across_ranks(broken, dist, True)
+        q.put((rank, a, b, c))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bench_cross_rank_parameter_check_two_ranks_gloo():
+    """bench.py's check behind the data-parallel legs: identical arenas pass, one differing
+    element on one rank or a NaN fails, on every rank alike."""
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_identity_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for _, a, b, c in results:
+        assert a["params_identical_across_ranks"] is True and a["ranks"] == 2
+        assert b["params_identical_across_ranks"] is False
+        assert c["params_identical_across_ranks"] is False
