@@ -954,7 +954,12 @@ def main() -> None:
         wl = None
         steps2, warm2 = max(1, min(args.steps, 50)), max(1, min(args.warmup, 10))
         failed = False
-        for key in ("infer", "train"):
+        # training first: its weight-gradient and projection streams are then the third and
+        # fourth streams this process puts work on (after the default stream and, in an N > 1
+        # run, the collective's), so with four hardware queues per process none of the streams
+        # the data-parallel step overlaps on has to share a queue; the inference leg's side
+        # stream comes last and only that leg can feel it
+        for key in ("train", "infer"):
             progress.update(leg=key)
             torch.cuda.empty_cache()
             try:
