@@ -487,7 +487,12 @@ class Train(Workload):
         self.net.load_state(model.init_state(self.net.specs, seed=3))
         multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
         if multi:
-            self.net.enable_data_parallel(32 << 20)
+            # PE_DP_TRANSPORT=bf16: gradients cross the links as bf16 (half the bytes); the
+            # default keeps them float32, as the reference's Horovod exchange does
+            self.transport = os.environ.get("PE_DP_TRANSPORT", "f32")
+            self.net.enable_data_parallel(32 << 20, transport=self.transport)
+            self.sharding = (f"data parallel: batch per rank, bucketed {self.transport} gradient "
+                             "all-reduce (RCCL) behind backward")
         self.host_replay = not multi and os.environ.get("PE_HOST_REPLAY", "0") == "1"
         macs, _, _ = flops.forward_macs(256, 192)
         self.flops_per_step = 3 * 2.0 * macs * self.batch   # backward = 2 x forward
