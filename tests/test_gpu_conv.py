@@ -230,3 +230,20 @@ def test_conv_chain_rejects_a_stage_that_is_not_pointwise():
     w3 = pnn.pack_conv_weight(rand_bf16((64, 64, 3, 3), g)).cuda()
     with pytest.raises(RuntimeError):
         pnn.conv2d_chain(x, [{"w": w3, "pad": 1}, {"w": w3, "pad": 1}])
+
+
+def test_conv_256_pixel_tile_with_full_epilogue():
+    """The 256 x 64 workgroup with scale, shift, residual and ReLU (a MobileNetV2 projection at
+    batch 256 has this shape class); random operands, the usual tolerance."""
+    B, H, W, cin, Cout = 22, 126, 96, 128, 64
+    g = torch.Generator().manual_seed(91)
+    x = rand_bf16((B, H, W, cin), g)
+    w = rand_bf16((Cout, cin, 1, 1), g, (2.0 / cin) ** 0.5)
+    scale = torch.rand(Cout, generator=g) + 0.5
+    shift = torch.randn(Cout, generator=g) * 0.1
+    res = rand_bf16((B, H, W, Cout), g)
+    got = pnn.conv2d(x.to(BF16).cuda(), pnn.pack_conv_weight(w).cuda(), scale.cuda(), shift.cuda(),
+                     res.to(BF16).cuda(), 1, 0, relu=True)
+    for b in (0, 13, B - 1):
+        ref = to.conv2d(x[b:b + 1], w, scale, shift, res[b:b + 1], 1, 0, relu=True)
+        close(got[b:b + 1], ref)
