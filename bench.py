@@ -475,7 +475,7 @@ class Train(Workload):
     bound = "mfma"
     kernel = "igemm_kernel + wgrad_kernel (all launches of one step)"
     peak = 2500.0
-    sharding = "data parallel: batch per rank, bucketed gradient all-reduce (RCCL) behind backward"
+    sharding = "data parallel: batch per rank; one rank, so no gradient exchange"
 
     def setup(self, device):
         import torch.distributed as dist
@@ -492,7 +492,7 @@ class Train(Workload):
             self.transport = os.environ.get("PE_DP_TRANSPORT", "f32")
             self.net.enable_data_parallel(32 << 20, transport=self.transport)
             self.sharding = (f"data parallel: batch per rank, bucketed {self.transport} gradient "
-                             "all-reduce (RCCL) behind backward")
+                             f"all-reduce ({backend_name(dist)}) behind backward")
         self.host_replay = not multi and os.environ.get("PE_HOST_REPLAY", "0") == "1"
         macs, _, _ = flops.forward_macs(256, 192)
         self.flops_per_step = 3 * 2.0 * macs * self.batch   # backward = 2 x forward
@@ -556,7 +556,7 @@ class HRNetTrain(Workload):
     bound = "mfma"
     kernel = "igemm_kernel + wgrad_kernel (all launches of one step)"
     peak = 2500.0
-    sharding = "data parallel: batch per rank, bucketed gradient all-reduce (RCCL) behind backward"
+    sharding = "data parallel: batch per rank; one rank, so no gradient exchange"
 
     def setup(self, device):
         import torch.distributed as dist
@@ -568,6 +568,8 @@ class HRNetTrain(Workload):
         multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
         if multi:
             self.net.enable_data_parallel(32 << 20)
+            self.sharding = ("data parallel: batch per rank, bucketed f32 gradient all-reduce "
+                             f"({backend_name(dist)}) behind backward")
         # PE_HIP_GRAPH=1 (one GPU only): replay the forward/loss/backward pass as a captured HIP
         # graph.  Measured slower than eager launches on this stack (44.5 vs 39.3 ms), so off.
         self.hip_graph = not multi and os.environ.get("PE_HIP_GRAPH") == "1"
@@ -628,7 +630,7 @@ class MobileNetTrain(Workload):
     bound = "hbm"
     kernel = "all launches of one step (depthwise, batch-norm and thin pointwise layers)"
     peak = 2500.0
-    sharding = "data parallel: batch per rank, bucketed gradient all-reduce (RCCL) behind backward"
+    sharding = "data parallel: batch per rank; one rank, so no gradient exchange"
 
     def setup(self, device):
         import torch.distributed as dist
@@ -640,6 +642,8 @@ class MobileNetTrain(Workload):
         multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
         if multi:
             self.net.enable_data_parallel(32 << 20)
+            self.sharding = ("data parallel: batch per rank, bucketed f32 gradient all-reduce "
+                             f"({backend_name(dist)}) behind backward")
         self.hip_graph = not multi and os.environ.get("PE_HIP_GRAPH") == "1"
         # PE_HOST_REPLAY (one GPU only): enqueue the pass from the call list recorded on the
         # first step instead of walking the Python graph
@@ -701,6 +705,8 @@ class MobileNetDetTrain(MobileNetTrain):
                                           det_blocks=self.net.det_blocks))
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
             self.net.enable_data_parallel(32 << 20)
+            self.sharding = ("data parallel: batch per rank, bucketed f32 gradient all-reduce "
+                             f"({backend_name(dist)}) behind backward")
         macs = mb.forward_macs(320, 320, K_JOINTS, len(mb.COCO_PAIRS)) + mb.detection_macs()
         self.flops_per_step = 3 * 2.0 * macs * self.batch
         rank = dist.get_rank() if dist.is_initialized() else 0
@@ -743,6 +749,21 @@ class MobileNetDetTrain(MobileNetTrain):
                           f"gradients, no loss, no optimizer), batch {B}, one run ({dt:.1f} s)"}
 
 
+def collective_env() -> dict:
+    """The environment a collective library reads, as this rank sees it."""
+    keys = ("NCCL_", "RCCL_", "HSA_", "GPU_MAX_HW_QUEUES", "TORCH_NCCL_", "PE_DP_", "HIP_VISIBLE",
+            "ROCR_VISIBLE", "CUDA_VISIBLE")
+    return {k: v for k, v in sorted(os.environ.items()) if k.startswith(keys)}
+
+
+def backend_name(dist) -> str:
+    """'RCCL' for torch.distributed's nccl backend on ROCm, else the backend's own name."""
+    if dist is None or not dist.is_initialized():
+        return "none"
+    b = dist.get_backend()
+    return "RCCL" if b == "nccl" else str(b)
+
+
 def _arena_identical_across_ranks(arena, dist, on_host):
     a = arena.detach().double()
     chk = torch.stack([a.sum(), a.abs().sum(), (a * a).sum()])
@@ -776,19 +797,55 @@ def launch_ranks(args) -> int:
         print(f"bench.py: --gpus {args.gpus} but only {ndev} GPU(s) are visible "
               "(PE_REHEARSE_ON_ONE_GPU=1 rehearses N ranks on one GPU over gloo)", file=sys.stderr)
         return 2
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    procs = []
-    for r in range(args.gpus):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus),
-                   LOCAL_WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port))
-        procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve()),
-                                       *sys.argv[1:]], env=env))
+    # The rendezvous port: bound here and handed to rank 0 still free but for the instant
+    # between close and re-bind; a second try with a fresh port covers the case that somebody
+    # took it in between (rank 0 then fails to bind and every rank exits within the init
+    # timeout).
     rc = 0
-    for pr in procs:
-        rc = max(rc, abs(pr.wait()))
+    for attempt in range(2):
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        procs = []
+        for r in range(args.gpus):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus),
+                       LOCAL_WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                       MASTER_PORT=str(port))
+            procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve()),
+                                           *sys.argv[1:]], env=env))
+        rc = _wait_ranks(procs)
+        if rc != EXIT_RENDEZVOUS:
+            break
+    return rc
+
+
+EXIT_RENDEZVOUS = 5     # a rank could not join the process group (nothing was measured)
+
+
+def _wait_ranks(procs, grace: float = 10.0) -> int:
+    """Waits for every rank.  As soon as one exits non-zero the others are told to stop
+    (SIGTERM, SIGKILL after `grace` seconds): ranks that lost a peer would otherwise sit in the
+    rendezvous or in a collective until its timeout.  Returns the first failing status, else 0.
+    Only the exact child processes started here are signalled."""
+    rc = 0
+    live = list(procs)
+    while live:
+        for pr in list(live):
+            st = pr.poll()
+            if st is None:
+                continue
+            live.remove(pr)
+            if st != 0 and rc == 0:
+                rc = abs(st)
+                for other in live:
+                    other.terminate()
+                t_end = time.monotonic() + grace
+                while any(o.poll() is None for o in live) and time.monotonic() < t_end:
+                    time.sleep(0.1)
+                for other in live:
+                    if other.poll() is None:
+                        other.kill()
+        time.sleep(0.05)
     return rc
 
 
@@ -802,6 +859,8 @@ def main() -> None:
     ap.add_argument("--no-also", action="store_true",
                     help="default workload only: skip the inference and training legs")
     ap.add_argument("--also-timeout", type=float, default=240.0)
+    ap.add_argument("--init-timeout", type=float, default=180.0,
+                    help="seconds a rank waits for the others in the rendezvous")
     args = ap.parse_args()
 
     if args.gpus < 1:
@@ -828,10 +887,32 @@ def main() -> None:
     if world > 1:
         import torch.distributed as dist
 
-        if rehearse:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=device)
+        from datetime import timedelta
+
+        backend = "gloo" if rehearse else "nccl"
+        step = f"init_process_group({backend!r})"
+        try:
+            if rehearse:
+                dist.init_process_group("gloo", timeout=timedelta(seconds=args.init_timeout))
+            else:
+                dist.init_process_group("nccl", device_id=device,
+                                        timeout=timedelta(seconds=args.init_timeout))
+            # the first collective builds the communicator (rings, channels, peer mappings):
+            # done here, by name, so that a failure is not mistaken for one of the workload's
+            step = f"first all_reduce over {backend}"
+            probe = torch.ones(1, device="cpu" if rehearse else device)
+            dist.all_reduce(probe)
+            if not rehearse:
+                torch.cuda.synchronize(device)
+            if int(probe.item()) != world:
+                raise RuntimeError(f"sum of ones over {world} ranks is {probe.item()}")
+        except Exception as exc:  # noqa: BLE001 - reported as the line, then a non-zero exit
+            msg = f"{step} failed on rank {rank}: {type(exc).__name__}: {exc}"[:600]
+            print(f"bench.py: {msg}", file=sys.stderr, flush=True)
+            if rank == 0:
+                print(json.dumps({"metric": METRIC, "value": None, "n_gpus": world,
+                                  "error": msg, "collective_env": collective_env()}), flush=True)
+            os._exit(EXIT_RENDEZVOUS)
         if dist.get_world_size() != args.gpus:
             raise SystemExit(f"process group has {dist.get_world_size()} ranks, --gpus {args.gpus}")
 
@@ -842,12 +923,14 @@ def main() -> None:
 
     progress = {"leg": args.workload, "phase": "setup", "step": -1}
 
-    def measure(wl, steps, warmup):
+    def measure(wl, steps, warmup, setup=True, spread=None):
         """W untimed steps, then exactly K steps between barrier + synchronize on both sides;
         (wall seconds, device milliseconds between HIP events on the launch stream), each the
-        maximum over ranks."""
-        progress.update(phase="setup", step=-1)
-        wl.setup(device)
+        maximum over ranks.  spread: a dict that receives the fastest and the slowest rank's
+        wall time per step (N > 1)."""
+        if setup:
+            progress.update(phase="setup", step=-1)
+            wl.setup(device)
         progress.update(phase="warmup")
         for i in range(warmup):
             progress["step"] = i
@@ -869,9 +952,40 @@ def main() -> None:
         if dist is not None:
             t = torch.tensor([elapsed, dev_ms], dtype=torch.float64,
                              device="cpu" if rehearse else device)
+            lo = t.clone()
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+            if spread is not None:
+                spread["rank_ms_per_step_min"] = float(lo[0]) * 1e3 / steps
+                spread["rank_ms_per_step_max"] = float(t[0]) * 1e3 / steps
             elapsed, dev_ms = float(t[0]), float(t[1])
         return elapsed, dev_ms
+
+    def exchange_report(wl, steps, warmup, ms_with):
+        """N > 1, a workload with a gradient exchange: the same ranks time the same step with
+        the exchange switched off (every rank keeps its local gradients), so the line states
+        how much of the step the all-reduce leaves exposed behind backward.  Runs after the
+        cross-rank parameter check: the ranks' parameters drift apart while it is off."""
+        net = getattr(wl, "net", None)
+        bk = getattr(net, "bucketer", None)
+        if dist is None or bk is None:
+            return None
+        rep = dict(bk.describe())
+        rep["collective_env"] = collective_env()
+        try:
+            bk.enabled = False
+            progress.update(phase="no-exchange")
+            e0, _ = measure(wl, steps, max(2, min(warmup, 5)), setup=False)
+            rep["ms_per_step_without_exchange"] = e0 * 1e3 / steps
+            rep["exchange_exposed_ms"] = ms_with - e0 * 1e3 / steps
+            # bytes each rank sends per step under a ring all-reduce, over the exposed time and
+            # over the whole step: lower bounds on what the links carried
+            ring = 2.0 * (world - 1) / world * rep["bytes_per_step"]
+            rep["ring_bytes_per_rank_per_step"] = int(ring)
+            rep["bus_gbs_over_step"] = ring / (ms_with * 1e-3) / 1e9
+        finally:
+            bk.enabled = True
+        return rep
 
     traffic_file = ROOT / "profiles" / "traffic.json"
     traffic = json.loads(traffic_file.read_text()) if traffic_file.exists() else {}
@@ -897,7 +1011,8 @@ def main() -> None:
         return rl
 
     wl = WORKLOADS[args.workload]()
-    elapsed, dev_ms = measure(wl, args.steps, args.warmup)
+    spread0 = {}
+    elapsed, dev_ms = measure(wl, args.steps, args.warmup, spread=spread0)
     out = None
     if rank == 0:
         out = {
@@ -923,10 +1038,16 @@ def main() -> None:
                        "sharding": getattr(wl, "sharding", "batch, no collective")},
             "roofline": roofline_of(wl, dev_ms / args.steps),
         }
+    if out is not None and spread0:
+        out.update(spread0)
     if dist is not None and hasattr(wl, "dp_check"):
         chk = wl.dp_check(dist, rehearse)       # a collective: every rank takes part
+        rep = exchange_report(wl, max(1, min(args.steps, 30)), args.warmup,
+                              elapsed * 1e3 / args.steps)
         if out is not None:
             out["dp_check"] = chk
+            if rep is not None:
+                out["exchange"] = rep
 
     # The metric also names network inference and the data-parallel training step.  A default
     # run measures them after the headline workload, with the same barrier-bracketed loop, and
@@ -969,7 +1090,8 @@ def main() -> None:
             torch.cuda.empty_cache()
             try:
                 w2 = WORKLOADS[key]()
-                e2, d2 = measure(w2, steps2, warm2)
+                spread2 = {}
+                e2, d2 = measure(w2, steps2, warm2, spread=spread2)
                 also[key] = {"value": world * w2.batch * steps2 / e2, "unit": "images/s",
                              "ms_per_step": e2 * 1e3 / steps2, "steps": steps2, "warmup": warm2,
                              "dtype": w2.dtype,
@@ -977,11 +1099,17 @@ def main() -> None:
                                         "sharding": getattr(w2, "sharding",
                                                             "batch, no collective")},
                              "roofline": roofline_of(w2, d2 / steps2)}
+                also[key].update(spread2)
                 if dist is not None and hasattr(w2, "dp_check"):
                     also[key]["dp_check"] = w2.dp_check(dist, rehearse)
+                    rep = exchange_report(w2, max(1, min(steps2, 30)), warm2, e2 * 1e3 / steps2)
+                    if rep is not None:
+                        also[key]["exchange"] = rep
                 legs.append((key, w2))
             except Exception as exc:  # noqa: BLE001 - recorded in the line, headline kept
-                also[key] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
+                also[key] = {"error": (f"{type(exc).__name__} in leg {key!r}, phase "
+                                       f"{progress['phase']!r}, step {progress['step']} "
+                                       f"(backend {backend_name(dist)}): {exc}")[:500]}
                 failed = True
                 break   # the ranks may no longer be in step: no further collectives
             finally:

@@ -57,8 +57,14 @@ int32_t pe_device_count(void);
  * at the cost of one hipLaunchKernel each.  The caller keeps every buffer the recorded calls
  * named alive and at the same address, and replays whatever it enqueued itself between the
  * recorded calls (pe_tape_length tells where in the tape it stood).  Entry points whose
- * arguments change from call to call (the optimizer's step number, pe_allreduce_bucket) are
- * left outside the recorded region.  One tape may record per thread at a time.
+ * arguments change from call to call (the optimizer's step number) are left outside the
+ * recorded region.  Two kinds of call REFUSE to run while the calling thread records
+ * (PE_E_UNSUPPORTED), because a replay of them would be silently wrong: pe_allreduce_bucket
+ * (RCCL enqueues the collective itself, only the scale kernel would land on the tape) and the
+ * one-launch batch-norm forms that take a `sync` buffer (pe_bn_finalize_apply_bf16,
+ * pe_bn_stats_apply_bf16, pe_bn_bwd_bf16 / pe_bn_bwd_from_partials_bf16 with sync != NULL:
+ * their arrival-counter base is a host-side count that a replay would not advance).
+ * One tape may record per thread at a time.
  * ------------------------------------------------------------------------ */
 typedef void* pe_tape_t;
 int32_t pe_tape_begin(void);
@@ -86,7 +92,14 @@ int32_t pe_stream_wait_stream(pe_stream_t waiter, pe_stream_t waited);
  *   (x,y)= (idx % W, idx / W); if refine != 0 and 1 < x < W-1 and 1 < y < H-1
  *          each coordinate moves 0.25 towards its larger neighbour (none on a
  *          tie); if conf <= 0 both are 0                  -> xy [B,K,2] float32
- * Inputs are assumed finite.
+ * Inputs are assumed finite.  What a map with non-finite elements gives is
+ * nevertheless fixed (every compare is an ordered float compare):
+ *   - a NaN never wins (numpy.argmax would return the first NaN): idx is the
+ *     lowest index of the largest non-NaN element above -inf;
+ *   - a map with no element above -inf (NaN and/or -inf only) gives idx 0,
+ *     conf = hm[0] (NaN if that is NaN) and xy = (0, 0);
+ *   - a NaN neighbour is neither larger nor smaller than the opposite one, so
+ *     the coordinate of that axis does not move.
  * ---------------------------------------------------------------------- */
 int32_t pe_decode_f32(const float* hm, int32_t B, int32_t K, int32_t H, int32_t W,
                       int64_t sB, int64_t sK, int64_t sH, int64_t sW,

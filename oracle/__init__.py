@@ -19,6 +19,7 @@ only reference-held facts they are pinned against are notebook outputs:
 """
 from .numpy_oracle import (  # noqa: F401
     decode_heatmaps,
+    decode_heatmaps_nan_skipped,
     gaussian_table,
     render_targets,
     render_vecmaps,

@@ -85,6 +85,47 @@ def decode_heatmaps(hm, refine: bool = True):
     return xy, conf, idx64.astype(np.int32)
 
 
+def decode_heatmaps_nan_skipped(hm, refine: bool = True):
+    """The decode rule for maps that hold NaN, where decode_heatmaps (numpy.argmax: the first
+    NaN wins) and an ordered compare part ways.  This is the rule pe_decode_f32 documents:
+
+      * a NaN never wins: idx is the lowest flat index of the largest non-NaN element that is
+        above -inf; a map with no such element (all NaN and/or -inf) answers idx 0 and
+        conf = hm[0] (which may itself be NaN), coordinates 0;
+      * in the quarter-pixel step a NaN neighbour is neither greater nor less than the other
+        one, so that axis does not move;
+      * conf <= 0 or NaN conf zeroes the coordinates.
+
+    Plain Python loops: for small test cases only.  On maps without NaN and without +-inf
+    neighbours it equals decode_heatmaps (tests/test_oracle.py)."""
+    hm = np.asarray(hm, dtype=F32)
+    B, K, H, W = hm.shape
+    xy = np.zeros((B, K, 2), F32)
+    conf = np.zeros((B, K), F32)
+    idx = np.zeros((B, K), np.int32)
+    for b in range(B):
+        for k in range(K):
+            m = hm[b, k]
+            best, bi = F32(-np.inf), -1
+            for i, v in enumerate(m.reshape(-1)):
+                if v > best:           # False for NaN; strict, so the first maximum is kept
+                    best, bi = v, i
+            if bi < 0:
+                bi, best = 0, m.reshape(-1)[0]
+            y, x = divmod(bi, W)
+            fx, fy = F32(x), F32(y)
+            if refine and 1 < x < W - 1 and 1 < y < H - 1:
+                r, l, d, u = m[y, x + 1], m[y, x - 1], m[y + 1, x], m[y - 1, x]
+                fx = F32(fx + F32(0.25) * F32(int(r > l) - int(r < l)))
+                fy = F32(fy + F32(0.25) * F32(int(d > u) - int(d < u)))
+            if not (best > 0):
+                fx = fy = F32(0)
+            xy[b, k] = (fx, fy)
+            conf[b, k] = best
+            idx[b, k] = bi
+    return xy, conf, idx
+
+
 # --------------------------------------------------------------------------
 # a2  Gaussian target rendering
 # --------------------------------------------------------------------------

@@ -408,10 +408,14 @@ def _hrnet_module_autograd(m, xs, unit, rb):
     return outs
 
 
-def hrnet_module_train_reference(m, state, xs_nhwc, douts_nhwc, bn_eps: float = 1e-5):
+def hrnet_module_train_reference(m, state, xs_nhwc, douts_nhwc, bn_eps: float = 1e-5,
+                                 acc64: bool = False):
     """Forward (batch statistics) + autograd backward of ONE exchange module on the CPU with
     bf16 rounding at the kernels' storage points.  xs / douts: float32 NHWC lists (one per
     branch / per fusion output) holding bf16 values.
+    acc64: the convolutions (forward and, through autograd, backward) accumulate in float64:
+    a second accumulation order over the same operands and rounding points, whose distance
+    from the float32 run measures how far summation order alone moves the results.
     Returns ([out NHWC], [dx NHWC], {name: grad in framework layout})."""
     rb, rw = _RoundBoth.apply, _RoundFwd.apply
     P = {}
@@ -420,7 +424,12 @@ def hrnet_module_train_reference(m, state, xs_nhwc, douts_nhwc, bn_eps: float = 
         for nm in (".weight", ".bn.gamma", ".bn.beta"):
             if u.name + nm not in P:
                 P[u.name + nm] = state[u.name + nm].clone().float().requires_grad_(True)
-        z = rb(F.conv2d(x, rw(P[u.name + ".weight"]), None, stride=u.stride, padding=u.k // 2))
+        w = rw(P[u.name + ".weight"])
+        if acc64:
+            z = rb(F.conv2d(x.double(), w.double(), None, stride=u.stride,
+                            padding=u.k // 2).float())
+        else:
+            z = rb(F.conv2d(x, w, None, stride=u.stride, padding=u.k // 2))
         y = F.batch_norm(z, None, None, P[u.name + ".bn.gamma"], P[u.name + ".bn.beta"],
                          training=True, momentum=0.0, eps=bn_eps)
         if residual is not None:

@@ -741,6 +741,11 @@ extern "C" int32_t pe_bn_finalize_apply_bf16(const void* workspace, int32_t rows
                PE_E_INVALID,
                "pe_bn_finalize_apply_bf16: tensors must be 16-byte aligned, scale / shift 32-byte, "
                "sync 128-byte");
+    // The arrival-counter base handed to the kernel comes from a host-side counter that
+    // advances per call; a launch replayed from a tape would carry a stale base and its
+    // consumer workgroups would not wait for the fold.
+    PE_REQUIRE(!pe::tape_recording(), PE_E_UNSUPPORTED,
+               "%s: the one-launch (sync) form cannot be recorded on a launch tape", "pe_bn_finalize_apply_bf16");
     const BnFwdOut o{mean, rstd, scale, shift, running_mean, running_var};
     const float unbias = M > 1 ? (float)((double)M / (double)(M - 1)) : 1.0f;
     const int nfold = (C + kFoldCh - 1) / kFoldCh;
@@ -792,6 +797,9 @@ extern "C" int32_t pe_bn_stats_apply_bf16(const void* z, int64_t M, int32_t C,
     PE_REQUIRE(z && workspace, PE_E_INVALID, "pe_bn_stats_apply_bf16: NULL pointer");
     PE_REQUIRE(aligned(z, 16) && aligned(workspace, 16), PE_E_INVALID,
                "pe_bn_stats_apply_bf16: z and workspace must be 16-byte aligned");
+    PE_REQUIRE(!pe::tape_recording(), PE_E_UNSUPPORTED,
+               "pe_bn_stats_apply_bf16: the one-launch (sync) form cannot be recorded on a "
+               "launch tape");
     const BnGeom g = bn_geom(M, C);
     pe::launch(bn_reduce_kernel<0>, g.nblk, 256, (size_t)g.rl * 2 * C * sizeof(float), as_stream(stream), static_cast<const uint16_t*>(z), nullptr, nullptr, nullptr, nullptr, 0.0f, M, C, g,
         static_cast<float*>(workspace));
@@ -834,6 +842,8 @@ extern "C" int32_t pe_bn_bwd_bf16(const void* da, const void* a, int32_t relu, c
                "pe_bn_bwd_bf16: relu must be 1 (ReLU) or 2 (ReLU6); it only matters when a is given");
     PE_REQUIRE((act_scale == nullptr) == (act_shift == nullptr) && !(a && act_scale), PE_E_INVALID,
                "pe_bn_bwd_bf16: give the stored activation a, or act_scale and act_shift, not both");
+    PE_REQUIRE(sync == nullptr || !pe::tape_recording(), PE_E_UNSUPPORTED,
+               "pe_bn_bwd_bf16: the one-launch (sync) form cannot be recorded on a launch tape");
     const float act_hi = relu == 2 ? 6.0f : INFINITY;
     const BnGeom g = bn_geom(M, C);
     float* partial = static_cast<float*>(workspace);
@@ -884,6 +894,9 @@ extern "C" int32_t pe_bn_bwd_from_partials_bf16(const void* g, const void* z, in
     const size_t cap = (pe_bn_workspace_bytes(M, C) - 256) / ((size_t)C * sizeof(float));
     PE_REQUIRE((size_t)rows * 2 + 3 <= cap, PE_E_INVALID,
                "pe_bn_bwd_from_partials_bf16: %d rows do not fit the workspace of (M, C)", rows);
+    PE_REQUIRE(sync == nullptr || !pe::tape_recording(), PE_E_UNSUPPORTED,
+               "pe_bn_bwd_from_partials_bf16: the one-launch (sync) form cannot be recorded on a "
+               "launch tape");
     float* partial = static_cast<float*>(workspace);
     float* coefA = coef_rows(partial + (size_t)rows * 2 * C);   // behind the rows the conv wrote
     float* coefB = coefA + C;

@@ -205,6 +205,11 @@ extern "C" int32_t pe_allreduce_bucket(pe_comm* comm, void* buf, int64_t n, int3
                "pe_allreduce_bucket: NULL pointer or empty bucket");
     PE_REQUIRE(dtype == PE_DTYPE_F32 || dtype == PE_DTYPE_BF16, PE_E_INVALID,
                "pe_allreduce_bucket: dtype must be PE_DTYPE_F32 or PE_DTYPE_BF16");
+    // RCCL enqueues the collective itself, so a launch tape would hold at most this entry
+    // point's own scale kernel: replaying that rescales the bucket without reducing it
+    PE_REQUIRE(!pe::tape_recording(), PE_E_UNSUPPORTED,
+               "pe_allreduce_bucket: a collective cannot be recorded on a launch tape; end the "
+               "tape before the gradient exchange");
     RcclApi* a = rccl_api();
     PE_REQUIRE(a != nullptr, PE_E_UNSUPPORTED, "pe_allreduce_bucket: librccl could not be loaded");
     hipStream_t st = as_stream(stream);

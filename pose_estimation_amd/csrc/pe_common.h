@@ -46,6 +46,7 @@ inline bool aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_
     } while (0)
 
 #ifdef __HIPCC__
+#include <atomic>
 #include <tuple>
 #include <utility>
 
@@ -98,6 +99,27 @@ template <class... P, class... A>
 inline void launch(void (*k)(P...), dim3 g, dim3 b, size_t lds, hipStream_t st, A&&... a) {
     if (tape_recording()) tape_push(new KernelRec<P...>(k, g, b, (unsigned)lds, st, a...));
     k<<<g, b, lds, st>>>(a...);
+}
+
+// Opt-in to more than 64 KB of dynamic LDS for `Kernel`.  The attribute belongs to the
+// (kernel, device) pair, so it is set once per device ordinal of the process, on the calling
+// thread's current device, and the result is kept: a failure is reported on every launch
+// attempt on that device, not only the first.
+template <auto Kernel>
+inline hipError_t ensure_dynamic_lds(int bytes) {
+    constexpr int kMaxDev = 64;
+    static std::atomic<int> state[kMaxDev];   // 0 = not set, 1 = set, 2 + hipError_t = failed
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= kMaxDev) return hipErrorInvalidDevice;
+    const int s = state[dev].load(std::memory_order_acquire);
+    if (s == 1) return hipSuccess;
+    if (s >= 2) return static_cast<hipError_t>(s - 2);
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(Kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    state[dev].store(e == hipSuccess ? 1 : 2 + static_cast<int>(e), std::memory_order_release);
+    return e;
 }
 
 inline hipError_t memset_async(void* dst, int value, size_t bytes, hipStream_t st) {

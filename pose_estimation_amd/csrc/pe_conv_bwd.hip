@@ -735,11 +735,10 @@ extern "C" int32_t pe_final_grad_prepare_bf16(const float* g_nchw, int32_t B, in
     const long npix = (long)B * HW;
     const size_t lds = (size_t)256 * (Kpad + 8) * sizeof(uint16_t);
     if (lds > 64 * 1024) {   // 160 KB of LDS per CU; anything above 64 KB is opt-in
-        static const hipError_t once = hipFuncSetAttribute(
-            reinterpret_cast<const void*>(&final_grad_prepare_kernel),
-            hipFuncAttributeMaxDynamicSharedMemorySize, 256 * (256 + 8) * (int)sizeof(uint16_t));
-        PE_REQUIRE(once == hipSuccess, PE_E_HIP, "pe_final_grad_prepare_bf16: LDS opt-in: %s",
-                   hipGetErrorString(once));
+        const hipError_t e = pe::ensure_dynamic_lds<&final_grad_prepare_kernel>(
+            256 * (256 + 8) * (int)sizeof(uint16_t));
+        PE_REQUIRE(e == hipSuccess, PE_E_HIP, "pe_final_grad_prepare_bf16: LDS opt-in: %s",
+                   hipGetErrorString(e));
     }
     pe::launch(final_grad_prepare_kernel, (unsigned)((npix + 255) / 256), 256, lds, as_stream(stream), g_nchw, npix, K, HW, Kpad, static_cast<uint16_t*>(out_nhwc));
     const int32_t rc = check_launch("pe_final_grad_prepare_bf16");

@@ -664,11 +664,10 @@ static int32_t launch_cfg(IgemmParams& p, long maxM, hipStream_t st, const char*
     constexpr size_t lds = lds_bytes<BM, BN, PIPE, WM * WN * 64, MASK>();
     static_assert(lds <= 160 * 1024, "tile does not fit the CU's LDS");
     if constexpr (lds > 64 * 1024) {
-        static const hipError_t once = hipFuncSetAttribute(
-            reinterpret_cast<const void*>(
-                &igemm_kernel<BM, BN, WM, PIPE, PF, MINB, MASK, WN, FAST, RES>),
-            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)once;
+        const hipError_t e = ensure_dynamic_lds<
+            &igemm_kernel<BM, BN, WM, PIPE, PF, MINB, MASK, WN, FAST, RES>>((int)lds);
+        PE_REQUIRE(e == hipSuccess, PE_E_HIP, "%s: LDS opt-in (%d bytes): %s", what, (int)lds,
+                   hipGetErrorString(e));
     }
     pe::launch(igemm_kernel<BM, BN, WM, PIPE, PF, MINB, MASK, WN, FAST, RES>, grid, WM * WN * 64, lds, st, p);
     return check_launch(what);

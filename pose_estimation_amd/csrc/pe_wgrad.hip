@@ -462,10 +462,9 @@ int32_t wgrad_launch(WgradParams& p, void* workspace, size_t workspace_bytes, hi
     {                                                                                     \
         constexpr size_t lds = NS_ == 1 ? lds1 : (size_t)NS_ * 2 * WG_TILE;              \
         if constexpr (lds > 64 * 1024) {                                                  \
-            static const hipError_t once = hipFuncSetAttribute(                           \
-                reinterpret_cast<const void*>(&wgrad_kernel<FLAT_, NS_>),                 \
-                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                    \
-            (void)once;                                                                   \
+            const hipError_t e = ensure_dynamic_lds<&wgrad_kernel<FLAT_, NS_>>((int)lds); \
+            PE_REQUIRE(e == hipSuccess, PE_E_HIP, "%s: LDS opt-in (%d bytes): %s", what,  \
+                       (int)lds, hipGetErrorString(e));                                   \
         }                                                                                 \
         pe::launch(wgrad_kernel<FLAT_, NS_>, grid, 256, lds, st, p);                              \
     }

@@ -286,13 +286,14 @@ class TrainGraph:
         self._tplan.run()
 
     def enable_data_parallel(self, bucket_bytes: int = 32 << 20, group=None, comm=None,
-                             transport: str = "f32") -> None:
+                             transport: str = "f32", exchange_when_alone: bool = False) -> None:
         """Call after torch.distributed is initialised (or pass comm = a parallel.NativeComm to
         exchange gradients through the library's own RCCL communicator); parameters must already
         be identical on every rank (same seed / same loaded state, or broadcast_parameters()).
         transport "bf16" halves the bytes on the links (gradients summed in bf16)."""
         self.bucketer = GradBucketer(self.grads, self.layer_starts, bucket_bytes, group,
-                                     comm=comm, transport=transport)
+                                     comm=comm, transport=transport,
+                                     exchange_when_alone=exchange_when_alone)
 
     def broadcast_parameters(self, src: int = 0) -> None:
         import torch.distributed as dist

@@ -405,7 +405,7 @@ def depthwise3x3_bwd_weight(x: torch.Tensor, dy: torch.Tensor, dw: torch.Tensor,
     if dw.dtype != torch.float32 or tuple(dw.shape) != (9, C) or not dw.is_contiguous():
         raise ValueError("dw must be contiguous float32 [9, C]")
     need = lib().pe_depthwise3x3_bwd_weight_workspace_bytes(C)
-    key = str(x.device)
+    key = _dev_key(x.device)
     ws = _dw_ws.get(key)
     if ws is None or ws.numel() < need:
         ws = torch.empty(need, dtype=torch.uint8, device=x.device)
@@ -794,11 +794,19 @@ def deconv4x4s2_bwd_data(dy: torch.Tensor, w_t: torch.Tensor,
 _wgrad_ws: dict = {}
 
 
+def _dev_key(device) -> str:
+    """One key per physical device: "cuda" means the current device."""
+    d = torch.device(device)
+    if d.type == "cuda" and d.index is None:
+        d = torch.device("cuda", torch.cuda.current_device())
+    return str(d)
+
+
 def wgrad_workspace(weight_elems: int, device) -> torch.Tensor:
     """Scratch for the split partial sums of the backward-weight GEMM (cached per device,
     grown on demand; calls on one stream reuse it safely)."""
     need = lib().pe_wgrad_workspace_bytes(int(weight_elems))
-    key = str(device)
+    key = _dev_key(device)
     ws = _wgrad_ws.get(key)
     if ws is None or ws.numel() < need:
         ws = torch.empty(need, dtype=torch.uint8, device=device)
@@ -810,12 +818,20 @@ def wgrad_batched_workspace(total_weight_elems: int, device) -> torch.Tensor:
     """Scratch for a batched weight-gradient launch (the same cached buffer as the single
     launches use, grown on demand)."""
     need = lib().pe_wgrad_batched_workspace_bytes(int(total_weight_elems))
-    key = str(device)
+    key = _dev_key(device)
     ws = _wgrad_ws.get(key)
     if ws is None or ws.numel() < need:
         ws = torch.empty(need, dtype=torch.uint8, device=device)
         _wgrad_ws[key] = ws
     return ws
+
+
+def live_scratch(device) -> list:
+    """The module-level scratch buffers of `device` as they are now.  A grown buffer replaces
+    its predecessor, which is then freed; whoever has stored a buffer's ADDRESS (a recorded
+    launch tape) must hold the tensor itself, and gets it from here."""
+    key = _dev_key(device)
+    return [d[key] for d in (_wgrad_ws, _dw_ws) if key in d]
 
 
 def _wgrad_elems(Cin: int, cout: int, k: int) -> int:

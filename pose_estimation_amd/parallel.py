@@ -130,7 +130,10 @@ class GradBucketer:
 
     def __init__(self, arena: torch.Tensor, boundaries: Sequence[int],
                  bucket_bytes: int = 32 << 20, group=None, tail_bytes: Optional[int] = None,
-                 comm: Optional["NativeComm"] = None, transport: str = "f32"):
+                 comm: Optional["NativeComm"] = None, transport: str = "f32",
+                 exchange_when_alone: bool = False):
+        """exchange_when_alone: issue the collectives even in a one-rank process group (a sum
+        over one rank changes nothing; this is how the RCCL path is exercised on one GPU)."""
         import torch.distributed as dist
 
         if transport not in ("f32", "bf16"):
@@ -149,6 +152,11 @@ class GradBucketer:
             self.world = dist.get_world_size(group) if dist.is_initialized() else 1
             backend = dist.get_backend(group) if dist.is_initialized() else "none"
         self.backend = backend
+        self.exchange_when_alone = bool(exchange_when_alone)
+        # enabled = False: layer_done() and finish() do nothing, every rank keeps its local
+        # gradients.  A measurement switch (the step without its exchange); the ranks'
+        # parameters drift apart while it is off.
+        self.enabled = True
         self._staged = (_HostStagedExchange(dist, group, arena.device)
                         if backend == "gloo" and arena.is_cuda else None)
         self._comm_stream = torch.cuda.Stream(device=arena.device) if comm is not None else None
@@ -171,6 +179,14 @@ class GradBucketer:
     def grad_scale(self) -> float:
         return 1.0 / self.world
 
+    def describe(self) -> dict:
+        """What one step puts on the links: for logs and benchmark lines."""
+        per = 2 if self.transport == "bf16" else self.arena.element_size()
+        sizes = [(end - start) * per for (start, end) in self.buckets]
+        return {"backend": self.backend, "world": self.world, "transport": self.transport,
+                "buckets": len(self.buckets), "bucket_bytes": sizes,
+                "bytes_per_step": int(sum(sizes))}
+
     # ---- one bucket ------------------------------------------------------------------
     def _pack(self, view: torch.Tensor, stage: torch.Tensor) -> None:
         from ._ffi import check, lib
@@ -187,7 +203,9 @@ class GradBucketer:
     def layer_done(self, layer_start: int) -> None:
         """Call after the gradient of the layer starting at `layer_start` (and of every layer
         above it) has been enqueued on the current stream."""
-        if self.world == 1 and self.comm is None:
+        if not self.enabled:
+            return
+        if self.world == 1 and self.comm is None and not self.exchange_when_alone:
             return
         b = self._ready_at.get(layer_start)
         if b is None:

@@ -88,8 +88,9 @@ class RecordedPass:
     stream current that was current while recording."""
 
     def __init__(self, fn: Callable, inputs: Sequence[Optional[torch.Tensor]],
-                 device: torch.device):
+                 device: torch.device, scratch: Optional[Callable[[], list]] = None):
         self.device = torch.device(device)
+        self.keep: list = []           # scratch that lives outside the pass but is on the tape
         self.static_in = [None if t is None else t.clone() for t in inputs]
         self.items: list = []          # (None, first, count) | (stream, func, args, kwargs)
         self.pool = torch.cuda.MemPool()
@@ -102,6 +103,15 @@ class RecordedPass:
             with torch.cuda.use_mem_pool(self.pool, device=self.device), _Recorder(self):
                 self.static_out = fn(*self.static_in)
             self._close_segment()
+            # The tape also addresses scratch the pass did not allocate: the module-level
+            # weight-gradient workspaces and the owner's batch-norm workspaces.  Those are
+            # replaced (and the old buffer freed) when a later, larger user makes them grow;
+            # holding the tensors that were current while recording keeps every recorded
+            # address valid for as long as this recording lives.
+            from . import nn as _nn
+            self.keep = list(_nn.live_scratch(self.device))
+            if scratch is not None:
+                self.keep += list(scratch())
         finally:
             check(self._lib.pe_tape_end(ctypes.byref(self._tape)))
         self.launches = sum(it[2] for it in self.items if it[0] is None)
@@ -171,6 +181,7 @@ class RecordedPass:
             self._tape = ctypes.c_void_p()
         self.items.clear()
         self.static_out = None
+        self.keep = []
 
     def __del__(self):
         try:
@@ -192,5 +203,6 @@ def run_recorded(cache: dict, net, fn: Callable, inputs: Sequence[Optional[torch
         fn(*inputs)
     finally:
         net.bn_momentum = momentum
-    rp = cache[key] = RecordedPass(fn, inputs, net.device)
+    rp = cache[key] = RecordedPass(fn, inputs, net.device,
+                                   scratch=lambda: list(getattr(net, "_ws", {}).values()))
     return rp.static_out

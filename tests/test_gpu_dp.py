@@ -43,6 +43,17 @@ def test_two_half_batches_equal_one_full_batch_with_frozen_batch_norm(which):
     assert out.count("images vs 1 x 8") == 2
 
 
+@pytest.mark.parametrize("which,transport", [("resnet", "f32"), ("resnet", "bf16"),
+                                             ("hrnet", "f32")])
+def test_torch_distributed_rccl_path_with_one_rank(which, transport):
+    """torch.distributed's nccl backend (= RCCL) itself, world size 1, exchange forced on: the
+    communicator is initialised with device_id, the asynchronous work handles are issued from
+    the weight-gradient stream and waited for before the optimizer; results must equal the
+    exchange-free run bit for bit.  What stays unexercised on a one-GPU box is N > 1 alone."""
+    out = _run(which, "rccl1", transport)
+    assert "gradients through RCCL equal the local ones" in out
+
+
 def test_bucketer_over_the_native_communicator_single_rank():
     """GradBucketer driven by the library's own RCCL communicator (pe_allreduce_bucket on a
     stream of its own, ordered by events): with one rank the exchanged arena equals the local
@@ -108,6 +119,16 @@ def test_bench_launches_its_own_ranks_and_refuses_to_misreport():
     rec = json.loads(lines[0])
     assert rec["n_gpus"] == 2 and rec["ranks"] == 2 and rec["collective_backend"] == "gloo"
     assert rec["config"]["workload"].startswith("resnet50_pose_train") and rec["value"] > 0
+    # the line names the backend that really ran and explains its own exchange
+    assert "(gloo)" in rec["config"]["sharding"] and "RCCL" not in rec["config"]["sharding"]
+    assert rec["dp_check"]["params_identical_across_ranks"] is True
+    ex = rec["exchange"]
+    assert ex["backend"] == "gloo" and ex["world"] == 2 and ex["buckets"] >= 4
+    assert ex["bytes_per_step"] == sum(ex["bucket_bytes"])
+    assert abs(ex["bytes_per_step"] - 136.0e6) < 2e6          # 34.0 M float32 gradients
+    assert ex["ms_per_step_without_exchange"] > 0 and "exchange_exposed_ms" in ex
+    assert isinstance(ex["collective_env"], dict)
+    assert 0 < rec["rank_ms_per_step_min"] <= rec["rank_ms_per_step_max"]
     # a launcher's world size that contradicts --gpus is refused too
     r = _bench("--gpus", "1", "--steps", "1", "--warmup", "0", "--no-also", "--no-cpu-baseline",
                env={"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})

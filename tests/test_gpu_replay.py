@@ -134,6 +134,57 @@ def test_host_replay_repeats_the_eager_steps_bit_for_bit(make, optimizer):
         assert torch.equal(a, b)
 
 
+def test_recorded_pass_survives_growth_of_the_shared_scratch_buffers():
+    """The tape holds the ADDRESS of the module-level weight-gradient workspace.  A second,
+    larger network makes that workspace grow, which frees the old buffer; the recording must
+    keep the buffer it recorded alive, or its later replays write split partial sums into
+    memory somebody else owns.  Net A replays two steps, net B (deeper: larger batched
+    weight-gradient jobs) trains eagerly and the freed memory is handed out and overwritten,
+    then A replays three more steps: bit for bit what five eager steps of A give."""
+    from pose_estimation_amd import nn as pnn
+
+    B, H, W = 4, 64, 64
+    jt = torch.from_numpy(synthetic.joints(B, 17, H, W, seed=2)).cuda()
+    mt = torch.from_numpy(synthetic.ignore_mask(B, H // 4, W // 4, seed=4)).cuda()
+    imgs = [torch.from_numpy(synthetic.images_u8(B, H, W, seed=60 + i)).cuda() for i in range(5)]
+
+    def steps(net, rng, use_replay):
+        out = []
+        for i in rng:
+            loss, _ = net.train_step(imgs[i], jt, mt, lr=1e-3, host_replay=use_replay)
+            out.append(loss.item())
+        return out
+
+    eager, _ = _resnet(seed=51)
+    want = steps(eager, range(5), False)
+    want_master = eager.master.clone()
+    del eager
+    pnn._wgrad_ws.clear()           # net A records against a workspace sized for net A alone
+    torch.cuda.empty_cache()
+
+    a, _ = _resnet(seed=51)
+    got = steps(a, range(2), True)
+    rp = next(iter(a._recorded.values()))
+    recorded_ws = [t for t in rp.keep if any(t is v for v in pnn._wgrad_ws.values())]
+    assert recorded_ws, "the recording does not hold the weight-gradient workspace"
+    old_ptr, old_size = recorded_ws[0].data_ptr(), recorded_ws[0].numel()
+
+    big = TrainablePoseResNet("cuda:0", num_joints=17, layers=(3, 4, 6, 3))
+    big.load_state(pm.init_state(big.specs, seed=7))
+    steps(big, range(2), False)
+    torch.cuda.synchronize()
+    now = pnn._wgrad_ws[pnn._dev_key("cuda:0")]
+    assert now.numel() > old_size and now.data_ptr() != old_ptr, "the workspace did not grow"
+    # whatever the allocator has free is handed out and overwritten
+    junk = [torch.full((n,), float("nan"), device="cuda") for n in (1 << 18, 1 << 20, 1 << 22, 1 << 24)]
+    torch.cuda.synchronize()
+    assert all(j.data_ptr() != old_ptr for j in junk)      # the recorded buffer was not re-issued
+    got += steps(a, range(2, 5), True)
+    torch.cuda.synchronize()
+    assert got == want
+    assert torch.equal(a.master, want_master)
+
+
 def test_host_replay_is_exclusive_with_the_gradient_exchange():
     net, _ = _hrnet(seed=3)
     net.bucketer = object()

@@ -85,6 +85,23 @@ def test_decode_known_answers():
     assert xy_nr[0, 3].tolist() == [3, 4]
 
 
+def test_decode_nan_rule_equals_plain_decode_without_nan_and_skips_nan():
+    hm = synthetic.decode_heatmaps(2, 4, 12, 10, seed=9)
+    for a, b in zip(oracle.decode_heatmaps_nan_skipped(hm), oracle.decode_heatmaps(hm)):
+        assert np.array_equal(a, b)
+    m = np.zeros((1, 3, 8, 8), np.float32)
+    m[0, 0, 3, 4] = 0.5
+    m[0, 0, 1, 1] = np.nan                 # a NaN elsewhere never wins
+    m[0, 1, 3, 4] = 0.5
+    m[0, 1, 3, 5] = np.nan                 # NaN neighbour: x stays, y moves towards 0.2
+    m[0, 1, 4, 4] = 0.2
+    m[0, 2] = np.nan                       # nothing but NaN: idx 0, conf NaN, xy 0
+    xy, conf, idx = oracle.decode_heatmaps_nan_skipped(m)
+    assert idx.tolist() == [[28, 28, 0]]
+    assert xy[0, 0].tolist() == [4.0, 3.0] and xy[0, 1].tolist() == [4.0, 3.25]
+    assert conf[0, 0] == 0.5 and np.isnan(conf[0, 2]) and xy[0, 2].tolist() == [0.0, 0.0]
+
+
 def test_decode_accepts_nhwc_views():
     hm = synthetic.decode_heatmaps(2, 3, 10, 8, seed=3)
     nhwc = np.ascontiguousarray(hm.transpose(0, 2, 3, 1))
