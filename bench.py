@@ -1008,6 +1008,14 @@ def main() -> None:
                 # the network steps move enough bytes for HBM to matter as much as the matrix
                 # cores: the measured traffic over this run's step time, against the HBM peak
                 rl["hbm_frac"] = rl["traffic"] / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+                alg = rec.get("algorithmic_bytes_per_launch")
+                if alg:
+                    # bytes the step must move if every tensor is touched once per pass that
+                    # needs it (flops.train_step_bytes / the forward's tensor bytes): what
+                    # the measured traffic is a multiple of, and the step's HBM floor
+                    rl["algorithmic_bytes"] = alg
+                    rl["traffic_over_algorithmic"] = rl["traffic"] / alg
+                    rl["hbm_floor_ms"] = alg / (HBM_PEAK_GBS * 1e9) * 1e3
         return rl
 
     wl = WORKLOADS[args.workload]()

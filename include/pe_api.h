@@ -731,6 +731,19 @@ int32_t pe_anchor_assign_f32(const float* anchors, int32_t A, const float* boxes
                              float ignore_iou, float* classes, float* weights, float* regs,
                              int32_t* match, pe_stream_t stream);
 
+/* One person box per image from its labelled keypoints, for batches that carry keypoints but
+ * no box annotation.  Replaces: the box the reference's dataset adapters read from the
+ * annotation files (dataset/pose_data.py, PoseEstimation.pyproj:27; absent); its format is what
+ * test.ipynb:571-572 prints: normalised corners (ymin, xmin, ymax, xmax) in [0, 1].
+ *   joints [B,K,3] float32 (x, y in input pixels, v); a joint counts when v > 0.
+ *   boxes  [B,1,4] = clamp((min y / H - margin, min x / W - margin, max y / H + margin,
+ *                          max x / W + margin), 0, 1), all zeros when no joint is labelled;
+ *   box_classes [B,1] int32 = 1, or 0 when no joint is labelled (an empty slot for
+ *   pe_anchor_assign_f32).  Exact (fixed float32 operation order). */
+int32_t pe_boxes_from_joints_f32(const float* joints, int32_t B, int32_t K, int32_t H, int32_t W,
+                                 float margin, float* boxes, int32_t* box_classes,
+                                 pe_stream_t stream);
+
 /* Loss of the detection branch (model/base_model.py, PoseEstimation.pyproj:30; absent):
  *   cls = sum_a weights * BCEwithLogits(logit, classes > 0) / N
  *   reg = sum_{positive a} sum_4 huber_1(reg_pred - regs) / N,  N = max(1, positives in batch)

@@ -29,6 +29,7 @@ from .numpy_oracle import (  # noqa: F401
     vecmap_loss_fwd_bwd,
     ssd_anchors,
     box_iou,
+    boxes_from_joints,
     anchor_assign,
     box_loss_fwd_bwd,
     mse_fwd_bwd,

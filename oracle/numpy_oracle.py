@@ -492,6 +492,29 @@ def ssd_anchors(levels=((20, 20), (10, 10)), scales=(0.35, 0.75), ratios=(0.5, 1
     return np.asarray(out, dtype=F32)
 
 
+def boxes_from_joints(joints, H: int, W: int, margin: float = 0.05):
+    """One person box per image from its labelled keypoints (v > 0): normalised corners
+    (ymin, xmin, ymax, xmax) = clamp(extent / size -+ margin, 0, 1), the format the reference's
+    `regs` rows print (test.ipynb:571-572); all zeros and class 0 when nothing is labelled.
+    The reference read its boxes from annotation files (dataset/pose_data.py,
+    PoseEstimation.pyproj:27; absent): this stands in for them on synthetic batches.
+    joints [B,K,3] float32 -> (boxes [B,1,4] float32, box_classes [B,1] int32)."""
+    j = np.asarray(joints, dtype=F32)
+    B = j.shape[0]
+    boxes = np.zeros((B, 1, 4), F32)
+    cls = np.zeros((B, 1), np.int32)
+    m, h, w = F32(margin), F32(H), F32(W)
+    for b in range(B):
+        vis = j[b, :, 2] > 0
+        if not vis.any():
+            continue
+        x, y = j[b, vis, 0], j[b, vis, 1]
+        box = np.array([y.min() / h - m, x.min() / w - m, y.max() / h + m, x.max() / w + m], F32)
+        boxes[b, 0] = np.minimum(np.maximum(box, F32(0)), F32(1))
+        cls[b, 0] = 1
+    return boxes, cls
+
+
 def box_iou(a, g) -> np.float32:
     """IoU of two corner boxes in float32, operations in the order the kernel uses."""
     iy0, ix0 = max(a[0], g[0]), max(a[1], g[1])

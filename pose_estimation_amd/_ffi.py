@@ -194,6 +194,9 @@ SIGNATURES = {
     "pe_anchor_assign_f32": (
         c_int32, [c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_int32, c_float, c_float,
                   c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "pe_boxes_from_joints_f32": (
+        c_int32, [c_void_p, c_int32, c_int32, c_int32, c_int32, c_float, c_void_p, c_void_p,
+                  c_void_p]),
     "pe_box_loss_workspace_bytes": (c_size_t, [c_int32]),
     "pe_box_loss_fwd_bwd": (
         c_int32, [c_void_p] * 5 + [c_int32, c_int32, c_float] + [c_void_p] * 5),

@@ -26,10 +26,19 @@ class Section:
         return f"Section({self.__dict__!r})"
 
 
+# The data set's keypoint vocabulary, in annotation order.  The reference selects the joints it
+# trains on BY NAME (`train_keypoints: ['left_wrist', 'right_wrist']`, test.ipynb:1013); its
+# annotation files are COCO-style (test.ipynb:41-44), whose person keypoints are these 17.
+COCO_KEYPOINTS = ["nose", "left_eye", "right_eye", "left_ear", "right_ear", "left_shoulder",
+                  "right_shoulder", "left_elbow", "right_elbow", "left_wrist", "right_wrist",
+                  "left_hip", "right_hip", "left_knee", "right_knee", "left_ankle", "right_ankle"]
+
+
 DEFAULTS: Dict[str, Dict[str, Any]] = {
     "data_config": {
         "synthetic": True,          # the reference's TFRecords are private; batches are synthetic
         "seed": 0,
+        "keypoints": None,          # names of the annotated joints; None = the 17 COCO names
     },
     "train_config": {               # test.ipynb:995-1014
         "batch_size": 2,
@@ -83,6 +92,44 @@ def parse_config(source: Union[str, Dict[str, Any], None] = None) -> Dict[str, S
     if unknown:
         raise KeyError(f"unknown config sections: {sorted(unknown)}")
     return {name: Section(_merge(DEFAULTS[name], raw.get(name) or {})) for name in DEFAULTS}
+
+
+def keypoint_names(data_cfg: Section, model_cfg: Section):
+    """The data set's keypoint names: `data_config.keypoints`, else the COCO names when the
+    model has 17 joints, else 'kp0', 'kp1', ..."""
+    names = data_cfg.get("keypoints")
+    if names:
+        return [str(n) for n in names]
+    k = int(model_cfg.get("num_joints", 17))
+    return list(COCO_KEYPOINTS) if k == 17 else [f"kp{i}" for i in range(k)]
+
+
+def select_keypoints(names, train_keypoints):
+    """`train_config.train_keypoints` (names, test.ipynb:1013) -> indices into `names`, in the
+    order given; None selects everything.  Unknown or repeated names are an error that lists
+    the vocabulary."""
+    if not train_keypoints:
+        return None
+    idx = []
+    for n in train_keypoints:
+        if n not in names:
+            raise KeyError(f"train_keypoints: {n!r} is not a keypoint of the data set {names}")
+        if names.index(n) in idx:
+            raise ValueError(f"train_keypoints: {n!r} is listed twice")
+        idx.append(names.index(n))
+    return idx
+
+
+def flip_permutation(names):
+    """For a left-right mirrored image: joint i of the output is joint perm[i] of the input.
+    'left_X' and 'right_X' swap when both are in `names`; everything else stays.  A name whose
+    partner is missing keeps its own row (there is no label to take over)."""
+    perm = list(range(len(names)))
+    for i, n in enumerate(names):
+        for a, b in (("left_", "right_"), ("right_", "left_")):
+            if n.startswith(a) and (b + n[len(a):]) in names:
+                perm[i] = names.index(b + n[len(a):])
+    return perm
 
 
 def learning_rate_at(train_cfg: Section, step: int) -> float:

@@ -260,9 +260,63 @@ __global__ __launch_bounds__(64) void box_loss_finish_kernel(const float* __rest
     loss[3] = (float)n;
 }
 
+// One person box per image from its labelled keypoints: one thread per image walks the K
+// joints in order (K is a few dozen), fixed float32 operation order.
+__global__ __launch_bounds__(64) void boxes_from_joints_kernel(const float* __restrict__ joints,
+                                                               int B, int K, float H, float W,
+                                                               float margin,
+                                                               float* __restrict__ boxes,
+                                                               int32_t* __restrict__ classes) {
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= B) return;
+    const float* j = joints + (long)b * K * 3;
+    float xmin = 0.0f, xmax = 0.0f, ymin = 0.0f, ymax = 0.0f;
+    bool any = false;
+    for (int k = 0; k < K; ++k) {
+        const float x = j[3 * k], y = j[3 * k + 1], v = j[3 * k + 2];
+        if (!(v > 0.0f)) continue;
+        if (!any) {
+            xmin = xmax = x;
+            ymin = ymax = y;
+            any = true;
+        } else {
+            xmin = fminf(xmin, x);
+            xmax = fmaxf(xmax, x);
+            ymin = fminf(ymin, y);
+            ymax = fmaxf(ymax, y);
+        }
+    }
+    float o[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (any) {
+        o[0] = ymin / H - margin;
+        o[1] = xmin / W - margin;
+        o[2] = ymax / H + margin;
+        o[3] = xmax / W + margin;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) o[i] = fminf(fmaxf(o[i], 0.0f), 1.0f);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) boxes[(long)b * 4 + i] = o[i];
+    classes[b] = any ? 1 : 0;
+}
+
 }  // namespace pe
 
 using namespace pe;
+
+extern "C" int32_t pe_boxes_from_joints_f32(const float* joints, int32_t B, int32_t K, int32_t H,
+                                            int32_t W, float margin, float* boxes,
+                                            int32_t* box_classes, pe_stream_t stream) {
+    const char* what = "pe_boxes_from_joints_f32";
+    PE_REQUIRE(B >= 0 && K > 0 && H > 0 && W > 0, PE_E_INVALID,
+               "%s: need B >= 0 and K, H, W > 0", what);
+    PE_REQUIRE(margin >= 0.0f && margin <= 1.0f, PE_E_INVALID, "%s: margin must be in [0, 1]", what);
+    if (B == 0) return PE_OK;
+    PE_REQUIRE(joints && boxes && box_classes, PE_E_INVALID, "%s: NULL pointer", what);
+    pe::launch(boxes_from_joints_kernel, (unsigned)((B + 63) / 64), 64, 0, as_stream(stream),
+               joints, B, K, (float)H, (float)W, margin, boxes, box_classes);
+    return check_launch(what);
+}
 
 extern "C" int32_t pe_anchor_assign_f32(const float* anchors, int32_t A, const float* boxes,
                                         const int32_t* box_classes, int32_t B, int32_t G,

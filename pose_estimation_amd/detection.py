@@ -106,17 +106,18 @@ def box_loss_fwd_bwd(logit: torch.Tensor, reg_pred: torch.Tensor, classes: torch
 def boxes_from_joints(joints: torch.Tensor, H: int, W: int, margin: float = 0.05):
     """One person box per image from its labelled keypoints, for batches that carry keypoints
     but no box annotation (synthetic data): the extent of the joints with v > 0, grown by
-    `margin` of the image on every side and clipped to it.
+    `margin` of the image on every side and clipped to it (pe_boxes_from_joints_f32).
     joints [B,K,3] float32 (x, y in input pixels, v) -> (boxes [B,1,4] float32 normalised
     (ymin, xmin, ymax, xmax), box_classes [B,1] int32: 1, or 0 when no joint is labelled)."""
-    x, y, v = joints[..., 0], joints[..., 1], joints[..., 2]
-    vis = v > 0
-    big = torch.finfo(torch.float32).max
-    xmin = torch.where(vis, x, torch.full_like(x, big)).amin(dim=1) / W - margin
-    xmax = torch.where(vis, x, torch.full_like(x, -big)).amax(dim=1) / W + margin
-    ymin = torch.where(vis, y, torch.full_like(y, big)).amin(dim=1) / H - margin
-    ymax = torch.where(vis, y, torch.full_like(y, -big)).amax(dim=1) / H + margin
-    any_vis = vis.any(dim=1)
-    box = torch.stack([ymin, xmin, ymax, xmax], dim=1).clamp(0.0, 1.0)
-    box = torch.where(any_vis[:, None], box, torch.zeros_like(box))
-    return box[:, None, :].contiguous(), any_vis.to(torch.int32)[:, None].contiguous()
+    _need_gpu(joints)
+    if joints.dtype != torch.float32 or joints.dim() != 3 or joints.shape[2] != 3 \
+            or not joints.is_contiguous():
+        raise ValueError("joints must be contiguous float32 [B,K,3]")
+    B, K, _ = joints.shape
+    boxes = torch.empty((B, 1, 4), dtype=torch.float32, device=joints.device)
+    cls = torch.empty((B, 1), dtype=torch.int32, device=joints.device)
+    with torch.cuda.device(joints.device):
+        check(lib().pe_boxes_from_joints_f32(joints.data_ptr(), B, K, int(H), int(W),
+                                             float(margin), boxes.data_ptr(), cls.data_ptr(),
+                                             _stream(joints)))
+    return boxes, cls

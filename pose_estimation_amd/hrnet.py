@@ -185,6 +185,61 @@ def forward_macs(spec: HRNetSpec, H: int = 384, W: int = 288) -> int:
     return res["macs"]
 
 
+def train_step_bytes(spec: HRNetSpec, batch: int = 64, H: int = 384, W: int = 288):
+    """Algorithmic HBM bytes of one training step (the denominator for measured step traffic):
+    flops.conv_train_bytes over the layer list, with the second conv of every residual unit and
+    the last conv of every fusion chain priced as residual layers (they read what they are
+    added to and write the sum; backward reads the other consumer's gradient), the uint8
+    images and their space-to-depth copy, the float32 heat maps through the loss and the
+    optimizer's 30 bytes per parameter.  Returns (total, {group: bytes})."""
+    from .flops import conv_train_bytes
+
+    g = {"convs": 0}
+    params = [0]
+
+    def run(u: Unit, h: int, w: int, residual: bool = False):
+        ho, wo = (h - 1) // u.stride + 1, (w - 1) // u.stride + 1
+        we = u.k * u.k * u.cin * u.cout
+        g["convs"] += conv_train_bytes(batch * h * w, max(u.cin, 8), batch * ho * wo, u.cout, we,
+                                       residual=residual)
+        params[0] += we + 2 * u.cout
+        return ho, wo
+
+    h, w = H, W
+    g["input"] = batch * H * W * 3 + 2 * batch * (H // 2) * (W // 2) * 16
+    for u in spec.stem:
+        h, w = run(u, h, w)
+    for b in spec.layer1:
+        run(b.c1, h, w)
+        run(b.c2, h, w)
+        run(b.c3, h, w, residual=True)
+        if b.down:
+            run(b.down, h, w)
+    sizes = [(h, w)]
+    for tr, mods in zip(spec.transitions, spec.stages):
+        new = []
+        for i, t in enumerate(tr):
+            src = sizes[i] if i < len(sizes) else sizes[-1]
+            new.append(run(t, *src) if t is not None else src)
+        sizes = new
+        for m in mods:
+            for i, br in enumerate(m.branches):
+                for blk in br:
+                    run(blk.c1, *sizes[i])
+                    run(blk.c2, *sizes[i], residual=True)
+            for row in m.fuse:
+                for j, chain in enumerate(row):
+                    s_ = sizes[j]
+                    for n, u in enumerate(chain or []):
+                        s_ = run(u, *s_, residual=(n == len(chain) - 1))
+    mo = batch * sizes[0][0] * sizes[0][1]
+    we = spec.widths[0] * spec.num_joints
+    g["final+loss"] = conv_train_bytes(mo, spec.widths[0], 0, 0, we, bn=False) \
+        + 4 * (4 * mo * spec.num_joints)
+    g["optimizer"] = 30 * (params[0] + we + spec.num_joints)
+    return sum(g.values()), g
+
+
 def init_state(spec: HRNetSpec, seed: int = 3) -> Dict[str, torch.Tensor]:
     """Random-init state dict in framework layouts (CPU float32): He-normal convs (fan-out),
     BN gamma 1 / beta 0 / running (0, 1), head N(0, 0.001) with zero bias."""

@@ -15,7 +15,8 @@ import numpy as np
 import torch
 
 from . import augment, ops, synthetic
-from .config import learning_rate_at, parse_config
+from .config import (flip_permutation, keypoint_names, learning_rate_at, parse_config,
+                     select_keypoints)
 from .model import init_state
 from .training import TrainablePoseResNet
 
@@ -29,6 +30,18 @@ class Trainer:
         if device is None:
             device = f"cuda:{int(os.environ.get('LOCAL_RANK', '0'))}"
         self.device = torch.device(device)
+        # The reference names the joints it trains on (`train_keypoints`, test.ipynb:1013): the
+        # names select rows of the data set's keypoint list, and their count is the number of
+        # heat maps the model predicts (it overrides model_config.num_joints).
+        self.keypoints = keypoint_names(self.data_cfg, self.model_cfg)
+        self.train_index = select_keypoints(self.keypoints, self.train_cfg.get("train_keypoints"))
+        if self.train_index is not None:
+            self.model_cfg.num_joints = len(self.train_index)
+            self.trained_keypoints = [self.keypoints[i] for i in self.train_index]
+        else:
+            self.trained_keypoints = list(self.keypoints)
+            self.model_cfg.num_joints = len(self.keypoints)    # an explicit name list decides
+        self._train_index_dev: Optional[torch.Tensor] = None
         self.net: Optional[TrainablePoseResNet] = None
         self.global_step = 0
         self._folded_at = -1     # global_step at which the inference constants were last folded
@@ -88,6 +101,29 @@ class Trainer:
             self.build_model()
         return self.net
 
+    # ------------------------------------------------------------------ keypoint subset
+    def _trained(self, joints: torch.Tensor) -> torch.Tensor:
+        """Rows of the trained keypoints out of joints [B, K_all, 3] (a gather; joints that
+        already hold only the trained rows pass through)."""
+        if self.train_index is None or joints.shape[1] == len(self.train_index):
+            return joints
+        if joints.shape[1] != len(self.keypoints):
+            raise ValueError(f"joints carry {joints.shape[1]} keypoints; the data set has "
+                             f"{len(self.keypoints)}, of which {len(self.train_index)} are trained")
+        if self._train_index_dev is None or self._train_index_dev.device != joints.device:
+            self._train_index_dev = torch.tensor(self.train_index, dtype=torch.int64,
+                                                 device=joints.device)
+        return joints.index_select(1, self._train_index_dev).contiguous()
+
+    def _flip_perm(self, k: int):
+        """Left/right relabelling for mirrored frames, by keypoint NAME: over the whole data
+        set's list when the joints still carry every keypoint, else over the trained ones."""
+        if k == len(self.keypoints):
+            return flip_permutation(self.keypoints)
+        if k == len(self.trained_keypoints):
+            return flip_permutation(self.trained_keypoints)
+        return None
+
     # ------------------------------------------------------------------ detection labels
     def _anchors(self, H: int, W: int) -> torch.Tensor:
         """Anchors of the two detection levels (strides 16 and 32: 20x20 and 10x10 cells, three
@@ -108,7 +144,15 @@ class Trainer:
 
         boxes, cls = detection.boxes_from_joints(joints, H, W)
         classes, weights, regs, _ = detection.anchor_assign(self._anchors(H, W), boxes, cls)
-        return {"classes": classes, "weights": weights, "regs": regs, "boxes": boxes}
+        out = {"classes": classes, "weights": weights, "regs": regs, "boxes": boxes}
+        # the reference also exposes the labels per feature level: `feat_1` = the 20x20x3
+        # anchors of the stride-16 map, `feat_2` = the 10x10x3 of the stride-32 map, each with
+        # its own classes / weights / regs (test.ipynb:538-541, 571-572).  Views, no copies.
+        n1 = (H // 16) * (W // 16) * 3
+        for name, sl in (("feat_1", slice(0, n1)), ("feat_2", slice(n1, classes.shape[1]))):
+            out[name] = {"classes": classes[:, sl], "weights": weights[:, sl],
+                         "regs": regs[:, sl]}
+        return out
 
     # ------------------------------------------------------------------ data (synthetic)
     def get_features_labels_data(self, num_batches: Optional[int] = None
@@ -120,7 +164,7 @@ class Trainer:
         if H % 32 or W % 32:
             raise ValueError(f"image_resize {H}x{W}: the network needs multiples of 32 "
                              "(five stride-2 stages down, three up)")
-        K = int(self.model_cfg.num_joints)
+        K = len(self.keypoints)          # every annotated joint; the trained ones are a subset
         s = int(self.model_cfg.heatmap_stride)
         sigma = float(self.model_cfg.sigma)
         i = 0
@@ -131,14 +175,17 @@ class Trainer:
             joints = torch.from_numpy(synthetic.joints(B, K, H, W, seed + 2)).to(self.device)
             mask = torch.from_numpy(synthetic.ignore_mask(B, H // s, W // s, seed + 4)).to(self.device)
             radius = self.model_cfg.get("radius")
-            hm, w = ops.render_targets(joints, H // s, W // s, float(s), sigma,
+            tj = self._trained(joints)
+            hm, w = ops.render_targets(tj, H // s, W // s, float(s), sigma,
                                        None if radius is None else int(radius), layout="NHWC")
             # the mask covers the frame it was drawn on; train_step warps it with the frame when
             # it resizes or augments
-            labels = {"heatmaps": hm, "joints": joints, "weights": w, "masks": mask}
+            labels = {"heatmaps": hm, "joints": joints, "weights": w, "masks": mask,
+                      "keypoints": list(self.trained_keypoints)}
             pairs = self.model_cfg.get("pairs")
-            if pairs:   # the reference's second dense label (test.ipynb:925-944)
-                labels["vecmaps"] = ops.render_vecmaps(joints, [tuple(p) for p in pairs], H // s,
+            if pairs:   # the reference's second dense label (test.ipynb:925-944); pair indices
+                #         count the TRAINED keypoints, as the notebook's do (test.ipynb:926)
+                labels["vecmaps"] = ops.render_vecmaps(tj, [tuple(p) for p in pairs], H // s,
                                                        W // s, float(s), layout="NHWC")
             if self.model_cfg.get("detection"):   # the third label group (test.ipynb:432)
                 labels["bboxes"] = self._bbox_labels(joints, H, W)
@@ -175,8 +222,7 @@ class Trainer:
                 prm = augment.resize_params(B, src_hw, (H, W))
             prm_t = torch.from_numpy(prm).to(images.device)
             x_s2d = augment.augment_u8(images, prm_t, (H, W))
-            perm = augment.COCO_FLIP_PERM if joints.shape[1] == 17 else None
-            joints = augment.transform_joints(joints, prm_t, W, perm)
+            joints = augment.transform_joints(joints, prm_t, W, self._flip_perm(joints.shape[1]))
             if mask is not None:
                 # the given mask covers the SOURCE frame in square cells; cells of the output
                 # frame that fall outside it are trained as background (fill = 1)
@@ -191,8 +237,9 @@ class Trainer:
         kw = {}
         if getattr(net, "det_blocks", None):
             if bb is None:
-                bb = self._bbox_labels(joints, H, W)
+                bb = self._bbox_labels(joints, H, W)     # the person box spans every joint
             kw["det_labels"] = (bb["classes"], bb["weights"], bb["regs"])
+        joints = self._trained(joints)
         lr = learning_rate_at(t, self.global_step)
         opt = t.optimizer
         params = opt.get("params", {})

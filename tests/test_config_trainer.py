@@ -57,6 +57,72 @@ def test_trainer_constructs_without_a_gpu():
     assert tr.train_cfg.batch_size == 4 and tr.net is None
 
 
+def test_train_keypoints_select_joints_by_name():
+    """`train_keypoints: ['left_wrist', 'right_wrist']` (test.ipynb:1013): names pick rows of the
+    data set's keypoint list and their count becomes the model's number of heat maps."""
+    from pose_estimation_amd import Trainer
+    from pose_estimation_amd import config as pc
+
+    tr = Trainer({"train_config": {"train_keypoints": ["left_wrist", "right_wrist"]}},
+                 device="cuda:0")
+    assert tr.train_index == [9, 10] and tr.model_cfg.num_joints == 2
+    assert tr.trained_keypoints == ["left_wrist", "right_wrist"]
+    assert tr._flip_perm(2) == [1, 0]                 # the two wrists swap under a mirror
+    assert tr._flip_perm(17) == [0, 2, 1, 4, 3, 6, 5, 8, 7, 10, 9, 12, 11, 14, 13, 16, 15]
+    tr = Trainer({"train_config": {"train_keypoints": ["right_knee", "nose"]}}, device="cuda:0")
+    assert tr.train_index == [14, 0] and tr._flip_perm(2) == [0, 1]   # partners not trained
+    # a data set with its own vocabulary (the reference's retail data had three keypoints)
+    tr = Trainer({"data_config": {"keypoints": ["head", "left_hand", "right_hand"]},
+                  "train_config": {"train_keypoints": ["right_hand"]}}, device="cuda:0")
+    assert tr.train_index == [2] and tr.model_cfg.num_joints == 1
+    tr = Trainer({"data_config": {"keypoints": ["head", "left_hand", "right_hand"]}},
+                 device="cuda:0")
+    assert tr.train_index is None and tr.model_cfg.num_joints == 3
+    with pytest.raises(KeyError, match="left_paw"):
+        Trainer({"train_config": {"train_keypoints": ["left_paw"]}}, device="cuda:0")
+    with pytest.raises(ValueError, match="twice"):
+        Trainer({"train_config": {"train_keypoints": ["nose", "nose"]}}, device="cuda:0")
+    assert pc.flip_permutation(["a", "left_b", "right_b", "left_c"]) == [0, 2, 1, 3]
+
+
+@pytest.mark.gpu
+def test_trainer_trains_only_the_named_keypoints():
+    """A reference-style config naming two joints: labels carry every annotated joint, the
+    heat maps and the model cover the two named ones; the labels of the named joints equal
+    what rendering just those rows gives; a mirrored frame swaps them by name."""
+    import numpy as np
+    import torch
+
+    import oracle
+    from pose_estimation_amd import Trainer
+
+    cfg = {"model_config": {"layers": [1, 1, 1, 1]},
+           "train_config": {"batch_size": 4, "preprocess": {"image_resize": [64, 64]},
+                            "train_keypoints": ["left_wrist", "right_wrist"]}}
+    tr = Trainer(cfg, device="cuda:0")
+    tr.build_model(seed=5)
+    feats, labels = next(iter(tr.get_features_labels_data(num_batches=1)))
+    assert tuple(labels["joints"].shape) == (4, 17, 3)
+    assert tuple(labels["heatmaps"].shape) == (4, 16, 16, 2)
+    assert labels["keypoints"] == ["left_wrist", "right_wrist"]
+    j = labels["joints"].cpu().numpy()
+    t, w = oracle.render_targets(j[:, [9, 10]], 16, 16, 4.0, 2.0, 6)
+    assert np.array_equal(labels["heatmaps"].cpu().numpy(), t.transpose(0, 2, 3, 1))
+    assert np.array_equal(labels["weights"].cpu().numpy(), w)
+    losses = [tr.train_step(feats, labels).item() for _ in range(6)]
+    assert np.isfinite(losses).all() and losses[-1] < losses[0]
+    hm = tr.predict(feats["images"])
+    assert tuple(hm.shape) == (4, 2, 16, 16)
+    xy, conf, idx = tr.decode(hm)
+    assert tuple(xy.shape) == (4, 2, 2)
+    # the same step fed the two trained rows directly gives the same loss as the full rows
+    tr_a = Trainer(cfg, device="cuda:0"); tr_a.build_model(seed=5)
+    tr_b = Trainer(cfg, device="cuda:0"); tr_b.build_model(seed=5)
+    la = tr_a.train_step(feats["images"], labels["joints"]).item()
+    lb = tr_b.train_step(feats["images"], labels["joints"][:, [9, 10]].contiguous()).item()
+    assert la == lb
+
+
 @pytest.mark.gpu
 def test_trainer_end_to_end(tmp_path):
     cfg = {"train_config": {"batch_size": 4, "preprocess": {"image_resize": [64, 96]}},

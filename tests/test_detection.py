@@ -154,6 +154,33 @@ def test_hip_box_loss_matches_oracle():
     assert float(l0[2]) == 0.0 and float(l0[3]) == 0.0 and not g0.any()
 
 
+def test_boxes_from_joints_oracle_known_answers():
+    j = np.zeros((3, 4, 3), np.float32)
+    j[0] = [[32, 64, 2], [96, 160, 1], [300, 300, 0], [64, 128, 2]]   # third joint unlabelled
+    j[1, :, 2] = 0                                                    # nothing labelled
+    j[2] = [[0, 0, 1], [319, 319, 1], [5, 5, 1], [9, 9, 1]]           # clipped on every side
+    boxes, cls = oracle.boxes_from_joints(j, 320, 320, 0.05)
+    assert cls.tolist() == [[1], [0], [1]]
+    assert np.allclose(boxes[0, 0], [0.2 - 0.05, 0.1 - 0.05, 0.5 + 0.05, 0.3 + 0.05], atol=1e-7)
+    assert boxes[1, 0].tolist() == [0, 0, 0, 0] and boxes[2, 0].tolist() == [0, 0, 1, 1]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,K,H,W,margin", [(64, 17, 320, 320, 0.05), (5, 3, 256, 192, 0.0),
+                                            (130, 17, 384, 288, 0.1), (1, 1, 64, 64, 0.05)])
+def test_hip_boxes_from_joints_matches_oracle_bit_for_bit(B, K, H, W, margin):
+    import torch
+
+    from pose_estimation_amd import detection, synthetic
+
+    j = synthetic.joints(B, K, H, W, seed=B + K)
+    j[B // 2, :, 2] = 0                                  # an image with nothing labelled
+    got_b, got_c = detection.boxes_from_joints(torch.from_numpy(j).cuda(), H, W, margin)
+    want_b, want_c = oracle.boxes_from_joints(j, H, W, margin)
+    assert np.array_equal(got_b.cpu().numpy(), want_b)
+    assert np.array_equal(got_c.cpu().numpy(), want_c)
+
+
 @pytest.mark.gpu
 def test_detection_argument_errors():
     a = torch.from_numpy(det.make_anchors()).cuda()

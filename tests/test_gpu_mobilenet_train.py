@@ -319,6 +319,19 @@ def test_trainer_with_the_reference_label_set():
     # and the positive anchor's regression row is that box (test.ipynb:571-572)
     pos = bb["classes"][0].argmax().item()
     assert torch.allclose(bb["regs"][0, pos], bb["boxes"][0, 0])
+    # the per-level groups the notebook indexes (test.ipynb:538-541, 571-572): feat_1 = the
+    # 20x20x3 anchors, feat_2 = the 10x10x3, views of the flat arrays
+    f1, f2 = bb["feat_1"], bb["feat_2"]
+    assert tuple(f1["classes"].shape) == (4, 1200) and tuple(f2["weights"].shape) == (4, 300)
+    assert tuple(f1["regs"].shape) == (4, 1200, 4) and tuple(f2["regs"].shape) == (4, 300, 4)
+    assert f1["classes"][0].reshape(20, 20, 3).shape == (20, 20, 3)        # the notebook's reshape
+    assert torch.equal(torch.cat([f1["classes"], f2["classes"]], 1), bb["classes"])
+    assert torch.equal(torch.cat([f1["regs"], f2["regs"]], 1), bb["regs"])
+    assert f1["weights"].data_ptr() == bb["weights"].data_ptr()
+    regs1 = f1["regs"][0].cpu().numpy()                                     # test.ipynb:571-572
+    rows = regs1[regs1[:, 2] - regs1[:, 0] > 0]
+    both = np.concatenate([rows, f2["regs"][0].cpu().numpy()[f2["classes"][0].cpu().numpy() > 0]])
+    assert len(both) == 1 and np.array_equal(both[0], bb["boxes"][0, 0].cpu().numpy())
     losses = [tr.train_step(feats, labels).item() for _ in range(4)]
     assert np.isfinite(losses).all() and losses[-1] < losses[0]
     heat, vec, (logit, reg) = tr.predict(feats["images"])
