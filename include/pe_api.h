@@ -310,6 +310,21 @@ int32_t pe_deconv4x4s2_fwd_bf16(int32_t B, int32_t H, int32_t W, int32_t Cin, in
                                 const float* scale, const float* shift, void* y,
                                 pe_stream_t stream);
 
+/* The transposed conv above followed by a 1x1 conv over its output (the pose head's last
+ * deconv + the final conv to K heat maps, model/mobilenet_pose.py, PoseEstimation.pyproj:31;
+ * absent), in ONE launch: the deconv's [B,2H,2W,Cout] output tile stays in LDS, only
+ *   out[b][k][y][x] = head_bias[k] + sum_c head_w[k][c] * bf16(relu?(deconv(x)*scale+shift))[b,y,x,c]
+ * is written, float32 NCHW [B,head_N,2H,2W].  Bit-identical to pe_deconv4x4s2_fwd_bf16 followed
+ * by pe_conv2d_fwd_bf16(out_f32_nchw = 1) on the same operands, without the 2 x B*4HW*Cout*2-byte
+ * round trip through memory.  Cout must be 128, 256, 384 or 512, Cin a multiple of 64,
+ * 1 <= head_N <= 32; partial sums over the first channel tiles are parked in out_f32_nchw itself;
+ * head_w is bf16 [head_N][Cout], 16-byte aligned; head_bias float32 [head_N] or NULL. */
+int32_t pe_deconv4x4s2_head_fwd_bf16(int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout,
+                                     int32_t relu, const void* x, const void* w_phases,
+                                     const float* scale, const float* shift, const void* head_w,
+                                     const float* head_bias, int32_t head_N, float* out_f32_nchw,
+                                     pe_stream_t stream);
+
 /* 7x7 stride-2 pad-3 stem on a 3-channel image, computed as a 4x4 stride-1 conv over the
  * 2x2 space-to-depth image: x_s2d [B,H/2,W/2,16] bf16 (12 real channels (ry,rx,c) + 4 zero),
  * w [Cout][4 rows][4 cols x 16] bf16 -> y [B,H/2,W/2,Cout]. */

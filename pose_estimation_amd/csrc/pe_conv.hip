@@ -240,14 +240,14 @@ extern "C" int32_t pe_conv2d_fwd_bnstats_bf16(const pe_conv_desc* d, const void*
     return conv2d_fwd_impl(d, x, w, nullptr, nullptr, nullptr, y, &sr, stream);
 }
 
-static int32_t deconv_fwd_impl(int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout,
-                               int32_t relu, const void* x, const void* w_phases,
-                               const float* scale, const float* shift, void* y,
-                               const StatReq* sr, pe_stream_t stream) {
+// The engine parameters of one transposed conv: the four output-parity phases of one launch.
+static int32_t deconv_fwd_params(int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout,
+                                 int32_t relu, const void* x, const void* w_phases,
+                                 const float* scale, const float* shift, void* y,
+                                 IgemmParams& p) {
     PE_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, PE_E_INVALID,
                "pe_deconv4x4s2_fwd_bf16: sizes must be positive");
     // the four output-parity phases run in one launch (gridDim.y = 4)
-    IgemmParams p;
     base_params(p);
     p.x = static_cast<const uint16_t*>(x);
     p.w = static_cast<const uint16_t*>(w_phases);
@@ -285,9 +285,39 @@ static int32_t deconv_fwd_impl(int32_t B, int32_t H, int32_t W, int32_t Cin, int
     p.osy = p.osx = 2;
     p.ldc = Cout;
     p.relu = relu;
-    const int32_t rc = attach_stats(p, sr, "pe_deconv4x4s2_fwd_bf16");
+    return PE_OK;
+}
+
+static int32_t deconv_fwd_impl(int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout,
+                               int32_t relu, const void* x, const void* w_phases,
+                               const float* scale, const float* shift, void* y,
+                               const StatReq* sr, pe_stream_t stream) {
+    IgemmParams p;
+    int32_t rc = deconv_fwd_params(B, H, W, Cin, Cout, relu, x, w_phases, scale, shift, y, p);
+    if (rc != PE_OK) return rc;
+    rc = attach_stats(p, sr, "pe_deconv4x4s2_fwd_bf16");
     if (rc != PE_OK) return rc;
     return igemm_launch(p, as_stream(stream), "pe_deconv4x4s2_fwd_bf16");
+}
+
+extern "C" int32_t pe_deconv4x4s2_head_fwd_bf16(int32_t B, int32_t H, int32_t W, int32_t Cin,
+                                                int32_t Cout, int32_t relu, const void* x,
+                                                const void* w_phases, const float* scale,
+                                                const float* shift, const void* head_w,
+                                                const float* head_bias, int32_t head_N,
+                                                float* out_f32_nchw, pe_stream_t stream) {
+    const char* what = "pe_deconv4x4s2_head_fwd_bf16";
+    PE_REQUIRE(x && w_phases && head_w && out_f32_nchw, PE_E_INVALID, "%s: NULL pointer", what);
+    IgemmParams p;
+    // (the layer's own output is never written; the engine's checks want a non-NULL y)
+    const int32_t rc = deconv_fwd_params(B, H, W, Cin, Cout, relu, x, w_phases, scale, shift,
+                                         out_f32_nchw, p);
+    if (rc != PE_OK) return rc;
+    p.head_w = static_cast<const uint16_t*>(head_w);
+    p.head_bias = head_bias;
+    p.head_out = out_f32_nchw;
+    p.head_N = head_N;
+    return igemm_head_launch(p, as_stream(stream), what);
 }
 
 extern "C" int32_t pe_deconv4x4s2_fwd_bf16(int32_t B, int32_t H, int32_t W, int32_t Cin,

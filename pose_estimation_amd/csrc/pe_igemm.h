@@ -64,6 +64,13 @@ struct IgemmParams {
     // from the stored activation (mask_a, same layout as the output; mask_sc / mask_sh unused),
     // and `res` may be set: the masked value is the GEMM's result plus the residual.
     const uint16_t* mask_a;
+    // Fused pointwise head (igemm_head_launch only): the layer's bf16 output tile stays in LDS
+    // and a 1x1 conv over ALL of its N channels (head_w [head_N][N] bf16, bias head_bias) is
+    // applied to it; only that conv's float32 NCHW result [B][head_N][OH*OW] is written.
+    const uint16_t* head_w;
+    const float* head_bias;
+    float* head_out;
+    int head_N;
     int32_t tap_info[kMaxTaps];  // dy | dx << 8 | slot << 16, packed by igemm_launch for the kernel
     // Optional phases (gridDim.y): phase i uses taps [ph_t0[i], ph_t0[i] + ph_T[i]), the row grid
     // ph_Ho[i] x ph_Wo[i], output offset (ph_ooy[i], ph_oox[i]) and weights w + ph_woff[i].
@@ -86,6 +93,10 @@ inline void igemm_defaults(IgemmParams& p) {
 
 // Launches the engine (asynchronous).  Returns PE_OK / PE_E_*.
 int32_t igemm_launch(const IgemmParams& p, hipStream_t st, const char* what);
+
+// The layer described by p (N == 256, single-pixel K runs that are multiples of 64) followed by
+// the 1x1 conv p.head_* over its output, in one launch; p.y is not written.
+int32_t igemm_head_launch(const IgemmParams& p, hipStream_t st, const char* what);
 
 // Up to kMaxChain layers over the same pixel tiles in one launch: stage s > 0 is a 1x1 stride-1
 // layer whose input is the output of stage s - 1 (see igemm_chain_kernel).

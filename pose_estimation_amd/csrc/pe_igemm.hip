@@ -81,7 +81,10 @@ __device__ __forceinline__ int xcd_tile_order(int bid, int nwg) {
 
 // One output tile: tile `bid` (in pixel-panel-major order, n-tiles of a panel adjacent) of
 // phase `ph`, computed by the whole workgroup in the LDS at `smem`.
-template <int BM, int BN, int WM, int PIPE, bool PF, bool MASK, int WN, bool FAST, bool RES>
+// HEAD: the epilogue keeps the bf16 output tile in LDS and multiplies it by the pointwise head
+// p.head_w (see igemm_head_kernel); nothing is stored to p.y.
+template <int BM, int BN, int WM, int PIPE, bool PF, bool MASK, int WN, bool FAST, bool RES,
+          bool HEAD = false>
 __device__ __forceinline__ void igemm_tile(const IgemmParams& p, char* smem, int bid, const int ph) {
     constexpr bool DB = PIPE == 1;    // the double buffer with draining barriers
     constexpr int NS = PIPE >= 2 ? PIPE : 0;   // ring stages
@@ -343,6 +346,169 @@ __device__ __forceinline__ void igemm_tile(const IgemmParams& p, char* smem, int
             multiply(smem);
             __syncthreads();  // everyone has read the tile before the next K step overwrites it
         }
+    }
+
+    if constexpr (HEAD) {
+        // Fused pointwise head.  Every wave has passed the K loop's last barrier, so the K tile
+        // is free: the bf16 output tile goes there in the activation-tile layout of the K loop
+        // (two planes of 64 channels, 128-byte rows, 16-byte slots swizzled by row & 7),
+        // written straight from the accumulators (a lane holds 4 consecutive channels of one
+        // pixel: one 8-byte store), and the head's weights for this tile's BN input channels sit
+        // behind it.  The values are what the unfused layer stores (same fmaf, ReLU and
+        // rounding), and the head's MFMAs run over the channels in the order a separate 1x1
+        // launch walks them, so the result is bit-identical to two launches.
+        static_assert(BM == 128 && BN == 128 && WM == 2 && WN == 2 && PIPE == 0 && !MASK,
+                      "the fused head is written for the single-stage 128 x 128 tile");
+        // The lane index as the epilogue sees it is opaque to the optimiser, so none of the
+        // epilogue's index arithmetic is computed (and kept in registers) ahead of the K loop.
+        int le = lane;
+        asm volatile("" : "+v"(le));
+        const int elr = le & 15, eq = le >> 4;
+        const int R = p.head_N;                       // weight rows (<= 32)
+        char* a3 = smem;
+        char* wfs = smem + 2 * BM * ROWB;             // [2][R][128 B]
+        // head weights of channels n0 .. n0+127: 2 planes x R rows x 8 chunks of 16 bytes
+        const int et = wid * 64 + le;
+        uint4 wreg[2];
+        int wdst[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int id = et + i * NT;
+            wdst[i] = -1;
+            if (id < 2 * R * 8) {
+                const int s = id / (R * 8), rem = id - s * (R * 8);
+                const int row = rem >> 3, ck = rem & 7;
+                wreg[i] = *reinterpret_cast<const uint4*>(p.head_w + (long)row * p.N + n0 + s * 64 +
+                                                          ck * 8);
+                wdst[i] = (s * R + row) * ROWB + ((ck ^ (row & 7)) << 4);
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < TN; ++a) {
+            const int c = a * 16 + eq * 4;            // channel inside this wave's plane
+            const int nn = n0 + wave_n * WCOLS + c;
+            f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+            if (p.scale) sc = *reinterpret_cast<const f32x4*>(p.scale + nn);
+            if (p.shift) sh = *reinterpret_cast<const f32x4*>(p.shift + nn);
+#pragma unroll
+            for (int b = 0; b < TM; ++b) {
+                const int row = wave_m * WROWS + b * 16 + elr;
+                float v0 = acc[a][b].x, v1 = acc[a][b].y, v2 = acc[a][b].z, v3 = acc[a][b].w;
+                if (p.scale || p.shift) {
+                    v0 = fmaf(v0, sc.x, sh.x);
+                    v1 = fmaf(v1, sc.y, sh.y);
+                    v2 = fmaf(v2, sc.z, sh.z);
+                    v3 = fmaf(v3, sc.w, sh.w);
+                }
+                if (p.relu) {
+                    v0 = fmaxf(v0, 0.0f); v1 = fmaxf(v1, 0.0f);
+                    v2 = fmaxf(v2, 0.0f); v3 = fmaxf(v3, 0.0f);
+                    if (p.relu == 2) {
+                        v0 = fminf(v0, 6.0f); v1 = fminf(v1, 6.0f);
+                        v2 = fminf(v2, 6.0f); v3 = fminf(v3, 6.0f);
+                    }
+                }
+                uint2 o;
+                o.x = pack_bf16x2(v0, v1);
+                o.y = pack_bf16x2(v2, v3);
+                *reinterpret_cast<uint2*>(a3 + wave_n * (BM * ROWB) + row * ROWB +
+                                          ((((c >> 3) ^ (row & 7)) << 4) | ((c & 7) << 1))) = o;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            if (wdst[i] >= 0) *reinterpret_cast<uint4*>(wfs + wdst[i]) = wreg[i];
+        // The accumulators are dead from here on.  The head's sums over the channel tiles
+        // before this one are parked in the head's own output (float32, written by this same
+        // thread a tile ago, so they come back from the L2) instead of in registers across the
+        // K loop: 16 registers fewer, which is what lets four workgroups share a CU.  The
+        // MFMA chain continues from the parked value, so the order of additions is still that
+        // of one launch over all channels.  Offsets are 32-bit (igemm_head_launch checks).
+        const int OHWh = p.OH * p.OW;
+        int hoff[2];                                  // element offset of (image, pixel), -1 = none
+#pragma unroll
+        for (int pt = 0; pt < 2; ++pt) {
+            const long m = m0 + (2 * wid + pt) * 16 + elr;
+            hoff[pt] = -1;
+            if (m < M) {
+                int bb, rem, oy, ox;
+                fast_divmod((int)m, HoWo, inv_howo, bb, rem);
+                fast_divmod(rem, Wo, inv_wo, oy, ox);
+                hoff[pt] = bb * R * OHWh + (oy * p.osy + ooy) * p.OW + ox * p.osx + oox;
+            }
+        }
+        f32x4 hacc[4];
+#pragma unroll
+        for (int pt = 0; pt < 2; ++pt)
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn) {
+                float v[4] = {0.f, 0.f, 0.f, 0.f};
+                if (tile_n > 0 && hoff[pt] >= 0) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int n = tn * 16 + eq * 4 + j;
+                        // agent-scope load: served by the L2 the store went to, never by a
+                        // line the CU's L1 may have kept from before it
+                        if (n < R)
+                            v[j] = __hip_atomic_load(p.head_out + (hoff[pt] + n * OHWh),
+                                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+                hacc[pt * 2 + tn] = f32x4{v[0], v[1], v[2], v[3]};
+            }
+        __syncthreads();
+        // wave `wid` multiplies pixel tiles 2*wid, 2*wid+1 (16 pixels each) by both 16-row
+        // weight tiles; rows past R read row R-1, their products are never stored
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                bf16x8 wf[2];
+#pragma unroll
+                for (int tn = 0; tn < 2; ++tn) {
+                    int wrow = tn * 16 + elr;
+                    wrow = wrow < R ? wrow : R - 1;
+                    wf[tn] = *reinterpret_cast<const bf16x8*>(
+                        wfs + (s * R + wrow) * ROWB + (((kk * 4 + eq) ^ (wrow & 7)) << 4));
+                }
+#pragma unroll
+                for (int pt = 0; pt < 2; ++pt) {
+                    const int row = (2 * wid + pt) * 16 + elr;
+                    const bf16x8 xf = *reinterpret_cast<const bf16x8*>(
+                        a3 + s * (BM * ROWB) + row * ROWB + (((kk * 4 + eq) ^ (elr & 7)) << 4));
+#pragma unroll
+                    for (int tn = 0; tn < 2; ++tn)
+                        hacc[pt * 2 + tn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                            wf[tn], xf, hacc[pt * 2 + tn], 0, 0, 0);
+                }
+            }
+        const bool last = tile_n == ntn - 1;
+#pragma unroll
+        for (int pt = 0; pt < 2; ++pt) {
+            if (hoff[pt] < 0) continue;
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn) {
+                const f32x4 hv = hacc[pt * 2 + tn];
+                const float v[4] = {hv.x, hv.y, hv.z, hv.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int n = tn * 16 + eq * 4 + j;
+                    if (n < R)
+                        p.head_out[hoff[pt] + n * OHWh] =
+                            (last && p.head_bias) ? v[j] + p.head_bias[n] : v[j];
+                }
+            }
+        }
+        // The next tile's K loop overwrites a3: every wave's LDS reads must be back, nothing
+        // more.  A raw barrier, because __syncthreads() would also wait for the stores above
+        // to complete (a microsecond or two per tile with nothing to overlap); they drain
+        // under the next tile's first loads instead.  This thread reads its parked sums back a
+        // whole K loop later, behind that loop's vmcnt(0) waits, which retire these older
+        // stores first.
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        return;
     }
 
     // ---- epilogue
@@ -896,6 +1062,58 @@ int32_t igemm_launch(const IgemmParams& pin, hipStream_t st, const char* what) {
 #undef PE_CFG_FAST
 #undef PE_CFG
     PE_REQUIRE(false, PE_E_UNSUPPORTED, "%s: no kernel for tile %dx%d wm %d db %d pf %d minb %d", what, bm, bn, wm, db, pf, minb);
+    return check_launch(what);
+}
+
+// ---- layer + pointwise head in one launch ----------------------------------------------------
+// A workgroup owns 128 GEMM rows (pixels) of one phase and walks BOTH 128-channel tiles of the
+// layer's 256 outputs, one after the other; after each it multiplies the bf16 tile it would have
+// stored by the head's weights for those channels (igemm_tile, HEAD), carrying the head's
+// accumulators across the two tiles.  The layer's output never reaches memory: for the last
+// transposed conv of the pose head that is a 2 x 402 MB round trip and a launch.
+template <int MINB>
+__global__ __launch_bounds__(256, MINB)
+__attribute__((amdgpu_waves_per_eu(MINB, MINB))) void igemm_head_kernel(const IgemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tile_m = xcd_tile_order(blockIdx.x, gridDim.x);
+    const int ntn = p.N / 128;
+#pragma unroll 1
+    for (int nt = 0; nt < ntn; ++nt) {
+        // opaque to the optimiser: otherwise everything that depends on the pixel tile alone
+        // is hoisted out of this loop and stays in registers across the epilogue, which then
+        // spills at four workgroups per CU
+        int bid = tile_m * ntn + nt;
+        asm volatile("" : "+s"(bid));
+        igemm_tile<128, 128, 2, 0, false, false, 2, true, false, true>(p, smem, bid, blockIdx.y);
+    }
+}
+
+int32_t igemm_head_launch(const IgemmParams& pin, hipStream_t st, const char* what) {
+    IgemmParams p = pin;
+    long maxM = 0;
+    {
+        const int32_t rc = igemm_prepare(p, maxM, what);
+        if (rc != PE_OK) return rc;
+    }
+    PE_REQUIRE(p.head_w && p.head_out && p.head_N >= 1 && p.head_N <= 32, PE_E_INVALID,
+               "%s: the head needs weights, an output and 1 to 32 channels", what);
+    PE_REQUIRE(aligned(p.head_w, 16) && aligned(p.head_out, 4), PE_E_INVALID,
+               "%s: head weights must be 16-byte aligned", what);
+    PE_REQUIRE(p.N % 128 == 0 && p.N <= 512 && igemm_fast_ok(p) && !p.res && !p.stat_partial && !p.mask_z &&
+                   p.out_mode == 0,
+               PE_E_UNSUPPORTED,
+               "%s: the fused head covers layers with 128, 256, 384 or 512 output channels, input "
+               "channels a multiple of 64, no residual and no statistics", what);
+    PE_REQUIRE((long)p.B * p.head_N * p.OH * p.OW < 0x7fffffffL, PE_E_UNSUPPORTED,
+               "%s: head output does not fit 32-bit element offsets", what);
+    const long ntm = (maxM + 127) / 128;
+    const dim3 grid((unsigned)ntm, (unsigned)p.nphase);
+    const size_t lds = (size_t)2 * 128 * ROWB + (size_t)2 * p.head_N * ROWB;
+    static const char* mb = getenv("PE_IGEMM_HEAD_MINB");   // tuning aid: 3 or 4 workgroups per CU
+    if (mb && atoi(mb) == 3)
+        pe::launch(igemm_head_kernel<3>, grid, 256, lds, st, p);
+    else
+        pe::launch(igemm_head_kernel<4>, grid, 256, lds, st, p);
     return check_launch(what);
 }
 

@@ -327,7 +327,7 @@ class PoseResNet:
             x = self._conv(b.c3, o, residual=idn, relu=True, **kw)
         return x
 
-    def forward_features(self, x_s2d: torch.Tensor) -> torch.Tensor:
+    def forward_features(self, x_s2d: torch.Tensor, skip_last_deconvs: int = 0) -> torch.Tensor:
         stem, blocks, deconvs, final = self.specs
         B = x_s2d.shape[0]
         ch, nb = self.front_chunk, min(self.front_blocks, len(blocks))
@@ -338,14 +338,35 @@ class PoseResNet:
             x = self._blocks(x, blocks[nb:], None)
         else:
             x = self._front(x_s2d, len(blocks), None)
-        for d in deconvs:
+        for d in deconvs[:len(deconvs) - skip_last_deconvs]:
             x = pnn.deconv4x4s2(x, self.w(d), self.scale[d.name], self.shift[d.name], True)
         return x
 
+    # PE_RESNET_FUSE_HEAD=1: the last transposed conv and the final 1x1 conv as ONE launch
+    # (pe_deconv4x4s2_head_fwd_bf16): the 256-channel map between them (402 MB at batch 256) is
+    # never written or read back.  Bit-identical to the two launches, and measured no faster at
+    # batch 256 (5.05 against 5.02 ms per forward): a workgroup has to walk both 128-channel
+    # tiles of its pixels one after the other, so the second pass re-reads its input tile 16 K
+    # steps after the first, when the L2 has long dropped it (two workgroups side by side share
+    # it while it is hot), and the epilogues no longer hide behind neighbours' K loops.  With
+    # the head's epilogue switched off altogether the launch still saved only 46-70 us of the
+    # 500 the two launches take, so it stays off by default.
+    fuse_head = os.environ.get("PE_RESNET_FUSE_HEAD", "0") == "1"
+
+    def _head_fusable(self) -> bool:
+        deconvs, final = self.specs[2], self.specs[3]
+        return (self.fuse_head and len(deconvs) > 0 and deconvs[-1].cout == 256
+                and deconvs[-1].cin % 64 == 0 and final.k == 1 and final.cout <= 32)
+
     def predict(self, images_u8: torch.Tensor) -> torch.Tensor:
         """uint8 [B,H,W,3] -> float32 heat maps [B,K,H/4,W/4] (inference, folded BN)."""
-        final = self.specs[3]
+        deconvs, final = self.specs[2], self.specs[3]
         x = pnn.preprocess_u8(images_u8)
+        if self._head_fusable():
+            x = self.forward_features(x, skip_last_deconvs=1)
+            d = deconvs[-1]
+            return pnn.deconv4x4s2_head(x, self.w(d), self.scale[d.name], self.shift[d.name],
+                                        self.w(final), self.shift[final.name], relu=True)
         x = self.forward_features(x)
         return self._conv(final, x, out_f32_nchw=True)
 

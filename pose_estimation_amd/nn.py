@@ -216,6 +216,31 @@ def deconv4x4s2(x: torch.Tensor, w_phases: torch.Tensor, scale=None, shift=None,
     return out
 
 
+def deconv4x4s2_head(x: torch.Tensor, w_phases: torch.Tensor, scale, shift, head_w: torch.Tensor,
+                     head_bias: Optional[torch.Tensor] = None, relu: bool = True,
+                     out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """deconv4x4s2 (+ scale, shift, ReLU) followed by a 1x1 conv head_w [K,1,1,Cout] (+ bias) in
+    one launch: x [B,H,W,Cin] -> float32 heat maps [B,K,2H,2W].  The deconv's output is never
+    written; the result equals deconv4x4s2 followed by conv2d(out_f32_nchw=True) bit for bit."""
+    _check_act(x)
+    _need_gpu(w_phases, scale, shift, head_w, head_bias, out)
+    B, H, W, Cin = x.shape
+    _, Cout, _, _ = w_phases.shape
+    if tuple(w_phases.shape) != (4, Cout, 4, Cin) or w_phases.dtype != BF16:
+        raise ValueError("w_phases must be bfloat16 [4,Cout,4,Cin]")
+    K = head_w.shape[0]
+    if head_w.dtype != BF16 or head_w.numel() != K * Cout or not head_w.is_contiguous():
+        raise ValueError("head_w must be contiguous bfloat16 [K,1,1,Cout]")
+    if out is None:
+        out = torch.empty((B, K, 2 * H, 2 * W), dtype=torch.float32, device=x.device)
+    with on_device(x):
+        check(lib().pe_deconv4x4s2_head_fwd_bf16(B, H, W, Cin, Cout, int(relu), x.data_ptr(),
+                                                 w_phases.data_ptr(), _ptr(scale), _ptr(shift),
+                                                 head_w.data_ptr(), _ptr(head_bias), K,
+                                                 out.data_ptr(), _stream(x)))
+    return out
+
+
 def stem7x7s2(x_s2d: torch.Tensor, w: torch.Tensor, scale=None, shift=None, relu: bool = True,
               out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """7x7/2 stem on the space-to-depth image: x_s2d [B,H/2,W/2,16] -> [B,H/2,W/2,Cout]."""

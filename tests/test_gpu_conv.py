@@ -132,6 +132,50 @@ def test_deconv_phases(case):
     close(got, ref)
 
 
+@pytest.mark.parametrize("case", [(3, 16, 12, 256, 17, 256), (2, 5, 7, 128, 17, 256),
+                                  (1, 32, 24, 256, 3, 256), (5, 9, 6, 64, 32, 256),
+                                  (2, 8, 6, 2048, 16, 256), (3, 7, 9, 64, 17, 128),
+                                  (2, 6, 5, 128, 5, 512)])
+def test_deconv_with_fused_pointwise_head(case):
+    """pe_deconv4x4s2_head_fwd_bf16: the last transposed conv of the pose head and the final 1x1
+    conv in one launch.  Bit for bit what the two launches give (the tile written to LDS holds
+    the values the deconv would store, and the head's MFMAs walk the channels in the same
+    order), and against the oracle: exact on integer operands."""
+    B, H, W, Cin, K, Cout = case
+    g = torch.Generator().manual_seed(31 + Cin + K)
+    x = rand_bf16((B, H, W, Cin), g)
+    w = rand_bf16((Cin, Cout, 4, 4), g, (1.0 / (Cin * 4)) ** 0.5)
+    scale = torch.rand(Cout, generator=g) + 0.5
+    shift = torch.randn(Cout, generator=g) * 0.1
+    hw = rand_bf16((K, Cout, 1, 1), g, 0.05)
+    bias = torch.randn(K, generator=g) * 0.1
+    xg, wg = x.to(BF16).cuda(), pnn.pack_deconv_weight(w).cuda()
+    hwg = pnn.pack_conv_weight(hw).cuda()
+    mid = pnn.deconv4x4s2(xg, wg, scale.cuda(), shift.cuda(), relu=True)
+    want = pnn.conv2d(mid, hwg, None, bias.cuda(), out_f32_nchw=True)
+    got = pnn.deconv4x4s2_head(xg, wg, scale.cuda(), shift.cuda(), hwg, bias.cuda(), relu=True)
+    assert got.shape == want.shape == (B, K, 2 * H, 2 * W)
+    assert torch.equal(got, want)
+    # without scale / shift / bias / ReLU, integer operands: exact against the oracle
+    xi = int_tensor((B, H, W, Cin), g, -2, 2)
+    wi = int_tensor((Cin, Cout, 4, 4), g, -1, 1)
+    hi = int_tensor((K, Cout, 1, 1), g, -1, 1)
+    midr = to.bf16r(to.deconv4x4s2(xi, wi))
+    ref = to.conv2d(midr, hi).permute(0, 3, 1, 2).contiguous()
+    goti = pnn.deconv4x4s2_head(xi.to(BF16).cuda(), pnn.pack_deconv_weight(wi).cuda(), None, None,
+                                pnn.pack_conv_weight(hi).cuda(), None, relu=False)
+    assert torch.equal(goti.cpu(), ref)
+
+
+def test_deconv_head_rejects_what_it_does_not_cover():
+    g = torch.Generator().manual_seed(3)
+    x = rand_bf16((1, 4, 4, 64), g).to(BF16).cuda()
+    w64 = pnn.pack_deconv_weight(rand_bf16((64, 64, 4, 4), g)).cuda()
+    hw = pnn.pack_conv_weight(rand_bf16((17, 64, 1, 1), g)).cuda()
+    with pytest.raises(RuntimeError, match="output channels"):
+        pnn.deconv4x4s2_head(x, w64, None, None, hw)
+
+
 def test_preprocess_and_stem():
     g = torch.Generator().manual_seed(11)
     B, H, W = 2, 64, 48
