@@ -332,6 +332,15 @@ int32_t pe_stem7x7s2_fwd_bf16(int32_t B, int32_t H2, int32_t W2, int32_t Cout, i
                               const void* x_s2d, const void* w, const float* scale,
                               const float* shift, void* y, pe_stream_t stream);
 
+/* The stem above (with ReLU) followed by the 3x3 stride-2 max pool, in ONE launch (inference):
+ * x_s2d [B,H2,W2,16] -> y_pooled [B,H2/2,W2/2,Cout]; the stem's own [B,H2,W2,Cout] map is
+ * never written.  Equals pe_maxpool3x3s2_fwd_bf16(pe_stem7x7s2_fwd_bf16(relu = 1)) bit for bit.
+ * Replaces the same reference code as the two entry points it fuses (nets/mobilenet_v2.py,
+ * PoseEstimation.pyproj:32; absent).  Cout must be 64; H2 and W2 even. */
+int32_t pe_stem7x7s2_pool_fwd_bf16(int32_t B, int32_t H2, int32_t W2, int32_t Cout,
+                                   const void* x_s2d, const void* w, const float* scale,
+                                   const float* shift, void* y_pooled, pe_stream_t stream);
+
 /* 3x3 stride-2 pad-1 stem on a 3-channel image (MobileNetV2's first conv; the reference's
  * backbone, nets/mobilenet_v2.py, PoseEstimation.pyproj:32, absent), computed over the same
  * space-to-depth image as a 2-row conv: w [Cout][2 rows][4 cols x 16] bf16 (columns 2, 3 zero),

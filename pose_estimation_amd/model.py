@@ -259,10 +259,21 @@ class PoseResNet:
                 h, w = (h - 1) // 2 + 1, (w - 1) // 2 + 1
         return B, h, w, self.specs[1][nblocks - 1].c3.cout
 
+    # The stem and the max pool as ONE launch (pe_stem7x7s2_pool_fwd_bf16): the stem's
+    # half-resolution map (402 MB at batch 256) is never written or read back.  Bit-identical
+    # to the two launches.  PE_RESNET_STEM_POOL=0: two launches (comparison).
+    fuse_stem_pool = os.environ.get("PE_RESNET_STEM_POOL", "1") != "0"
+
     def _front(self, x_s2d: torch.Tensor, nblocks: int, out: Optional[torch.Tensor]) -> torch.Tensor:
         stem, blocks, _, _ = self.specs
-        x = pnn.stem7x7s2(x_s2d, self.w(stem), self.scale[stem.name], self.shift[stem.name], True)
-        x = pnn.maxpool3x3s2(x)
+        if (self.fuse_stem_pool and stem.cout == 64 and x_s2d.shape[1] % 2 == 0
+                and x_s2d.shape[2] % 2 == 0):
+            x = pnn.stem7x7s2_pool(x_s2d, self.w(stem), self.scale[stem.name],
+                                   self.shift[stem.name])
+        else:
+            x = pnn.stem7x7s2(x_s2d, self.w(stem), self.scale[stem.name], self.shift[stem.name],
+                              True)
+            x = pnn.maxpool3x3s2(x)
         return self._blocks(x, blocks[:nblocks], out)
 
     # Chained bottlenecks (PE_RESNET_CHAIN=1): in the stages whose 3x3 conv has 64 output

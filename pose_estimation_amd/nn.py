@@ -258,6 +258,26 @@ def stem7x7s2(x_s2d: torch.Tensor, w: torch.Tensor, scale=None, shift=None, relu
     return out
 
 
+def stem7x7s2_pool(x_s2d: torch.Tensor, w: torch.Tensor, scale=None, shift=None,
+                   out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """stem7x7s2 (+ scale, shift, ReLU) followed by maxpool3x3s2 in one launch:
+    x_s2d [B,H/2,W/2,16] -> [B,H/4,W/4,64].  The stem's own output is never written; the result
+    equals maxpool3x3s2(stem7x7s2(x_s2d, ..., relu=True)) bit for bit."""
+    _check_act(x_s2d, "x_s2d")
+    _need_gpu(w, scale, shift, out)
+    B, H2, W2, C = x_s2d.shape
+    Cout = w.shape[0]
+    if C != 16 or tuple(w.shape) != (Cout, 4, 64) or w.dtype != BF16:
+        raise ValueError("stem expects x_s2d [...,16] and w bfloat16 [Cout,4,64]")
+    if out is None:
+        out = torch.empty((B, H2 // 2, W2 // 2, Cout), dtype=BF16, device=x_s2d.device)
+    with on_device(x_s2d):
+        check(lib().pe_stem7x7s2_pool_fwd_bf16(B, H2, W2, Cout, x_s2d.data_ptr(), w.data_ptr(),
+                                               _ptr(scale), _ptr(shift), out.data_ptr(),
+                                               _stream(x_s2d)))
+    return out
+
+
 def conv2d_bnstats(x: torch.Tensor, w: torch.Tensor, ws: torch.Tensor, stride: int = 1,
                    pad: int = 0, out: Optional[torch.Tensor] = None, kw: Optional[int] = None):
     """z = conv(x, w) with the per-channel sums of z and z*z left in `ws` as one partial row per

@@ -201,6 +201,33 @@ def test_preprocess_and_stem():
     assert torch.equal(goti.float().cpu(), refi)
 
 
+@pytest.mark.parametrize("case", [(2, 64, 48), (3, 128, 96), (1, 16, 12), (2, 40, 72), (1, 8, 4),
+                                  (5, 36, 68)])
+def test_stem_and_pool_in_one_launch(case):
+    """pe_stem7x7s2_pool_fwd_bf16 against the two launches it replaces, bit for bit (sizes that
+    are and are not whole numbers of 4 x 16 pooled tiles), and against the oracle on integer
+    operands."""
+    B, H, W = case                      # image size; the stem works at H/2 x W/2
+    g = torch.Generator().manual_seed(17 + H + W)
+    img = torch.randint(0, 256, (B, H, W, 3), generator=g, dtype=torch.uint8)
+    xs = pnn.preprocess_u8(img.cuda())
+    w = rand_bf16((64, 3, 7, 7), g, 0.1)
+    scale = torch.rand(64, generator=g) + 0.5
+    shift = torch.randn(64, generator=g) * 0.3
+    wp = pnn.pack_stem_weight(w).cuda()
+    for sc, sh in ((scale.cuda(), shift.cuda()), (None, None), (None, shift.cuda())):
+        want = pnn.maxpool3x3s2(pnn.stem7x7s2(xs, wp, sc, sh, relu=True))
+        got = pnn.stem7x7s2_pool(xs, wp, sc, sh)
+        assert got.shape == want.shape == (B, H // 4, W // 4, 64)
+        assert torch.equal(got, want)
+    xi = int_tensor((B, H, W, 3), g, -2, 2)
+    wi = int_tensor((64, 3, 7, 7), g, -1, 1)
+    ref = to.maxpool3x3s2(to.bf16r(torch.relu(to.conv2d(xi, wi, stride=2, pad=3))))
+    xsi = torch.from_numpy(to.space_to_depth16(xi.numpy())).to(BF16).cuda()
+    goti = pnn.stem7x7s2_pool(xsi, pnn.pack_stem_weight(wi).cuda())
+    assert torch.equal(goti.float().cpu(), ref)
+
+
 def test_maxpool():
     g = torch.Generator().manual_seed(13)
     x = rand_bf16((3, 16, 12, 64), g)
