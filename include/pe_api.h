@@ -341,6 +341,15 @@ int32_t pe_stem7x7s2_pool_fwd_bf16(int32_t B, int32_t H2, int32_t W2, int32_t Co
                                    const void* x_s2d, const void* w, const float* scale,
                                    const float* shift, void* y_pooled, pe_stream_t stream);
 
+/* 3x3 stride-1 pad-1 conv with 64 input and 64 output channels (+ scale, shift, relu as in
+ * pe_conv2d_fwd_bf16), x, y [B,H,W,64] bf16 NHWC, w [64][3][3][64] bf16: the 3x3 layers of the
+ * first backbone stage (nets/mobilenet_v2.py, PoseEstimation.pyproj:32; absent) for inference.
+ * One persistent workgroup per CU keeps the whole filter in LDS and stages each input patch
+ * once instead of once per tap.  Equals pe_conv2d_fwd_bf16 on the same operands bit for bit. */
+int32_t pe_conv3x3_c64_fwd_bf16(int32_t B, int32_t H, int32_t W, const void* x, const void* w,
+                                const float* scale, const float* shift, int32_t relu, void* y,
+                                pe_stream_t stream);
+
 /* 3x3 stride-2 pad-1 stem on a 3-channel image (MobileNetV2's first conv; the reference's
  * backbone, nets/mobilenet_v2.py, PoseEstimation.pyproj:32, absent), computed over the same
  * space-to-depth image as a 2-row conv: w [Cout][2 rows][4 cols x 16] bf16 (columns 2, 3 zero),

@@ -194,6 +194,8 @@ SIGNATURES = {
     "pe_anchor_assign_f32": (
         c_int32, [c_void_p, c_int32, c_void_p, c_void_p, c_int32, c_int32, c_float, c_float,
                   c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "pe_conv3x3_c64_fwd_bf16": (
+        c_int32, [c_int32] * 3 + [c_void_p] * 4 + [c_int32, c_void_p, c_void_p]),
     "pe_stem7x7s2_pool_fwd_bf16": (
         c_int32, [c_int32] * 4 + [c_void_p] * 6),
     "pe_deconv4x4s2_head_fwd_bf16": (

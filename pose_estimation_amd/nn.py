@@ -258,6 +258,23 @@ def stem7x7s2(x_s2d: torch.Tensor, w: torch.Tensor, scale=None, shift=None, relu
     return out
 
 
+def conv3x3_c64(x: torch.Tensor, w: torch.Tensor, scale=None, shift=None, relu: int = 1,
+                out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """3x3 stride-1 pad-1 conv, 64 -> 64 channels, through the resident-filter kernel
+    (pe_conv3x3_c64_fwd_bf16): equals conv2d(x, w, scale, shift, None, 1, 1, relu) bit for bit."""
+    _check_act(x)
+    _need_gpu(w, scale, shift, out)
+    B, H, W, C = x.shape
+    if C != 64 or tuple(w.shape) != (64, 3, 3, 64) or w.dtype != BF16 or not w.is_contiguous():
+        raise ValueError("conv3x3_c64 expects x [...,64] and w contiguous bfloat16 [64,3,3,64]")
+    if out is None:
+        out = torch.empty((B, H, W, 64), dtype=BF16, device=x.device)
+    with on_device(x):
+        check(lib().pe_conv3x3_c64_fwd_bf16(B, H, W, x.data_ptr(), w.data_ptr(), _ptr(scale),
+                                            _ptr(shift), int(relu), out.data_ptr(), _stream(x)))
+    return out
+
+
 def stem7x7s2_pool(x_s2d: torch.Tensor, w: torch.Tensor, scale=None, shift=None,
                    out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """stem7x7s2 (+ scale, shift, ReLU) followed by maxpool3x3s2 in one launch:

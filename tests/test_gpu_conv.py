@@ -201,6 +201,30 @@ def test_preprocess_and_stem():
     assert torch.equal(goti.float().cpu(), refi)
 
 
+@pytest.mark.parametrize("case", [(2, 64, 48), (5, 16, 16), (1, 7, 5), (3, 33, 50), (300, 16, 12)])
+def test_conv3x3_64_channels_resident_filter_kernel(case):
+    """pe_conv3x3_c64_fwd_bf16 against the engine on the same operands, bit for bit (whole and
+    part-filled 16 x 16 tiles, more tiles than CUs), and against the oracle: exact on integer
+    operands."""
+    B, H, W = case
+    g = torch.Generator().manual_seed(5 + H + W)
+    x = rand_bf16((B, H, W, 64), g).to(BF16).cuda()
+    w = rand_bf16((64, 64, 3, 3), g, (2.0 / 576) ** 0.5)
+    wp = pnn.pack_conv_weight(w).cuda()
+    scale = (torch.rand(64, generator=g) + 0.5).cuda()
+    shift = (torch.randn(64, generator=g) * 0.1).cuda()
+    for sc, sh, relu in ((scale, shift, 1), (None, None, 0), (None, shift, 2)):
+        want = pnn.conv2d(x, wp, sc, sh, None, 1, 1, relu)
+        got = pnn.conv3x3_c64(x, wp, sc, sh, relu)
+        assert torch.equal(got, want), (sc is not None, relu)
+    if B <= 5:
+        xi = int_tensor((B, H, W, 64), g, -2, 2)
+        wi = int_tensor((64, 64, 3, 3), g, -1, 1)
+        ref = to.bf16r(to.conv2d(xi, wi, stride=1, pad=1))
+        goti = pnn.conv3x3_c64(xi.to(BF16).cuda(), pnn.pack_conv_weight(wi).cuda(), relu=0)
+        assert torch.equal(goti.float().cpu(), ref)
+
+
 @pytest.mark.parametrize("case", [(2, 64, 48), (3, 128, 96), (1, 16, 12), (2, 40, 72), (1, 8, 4),
                                   (5, 36, 68)])
 def test_stem_and_pool_in_one_launch(case):
