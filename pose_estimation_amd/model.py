@@ -239,17 +239,7 @@ class PoseResNet:
         return self._side
 
     # ------------------------------------------------------------------ inference
-    # 3x3 stride-1 64 -> 64 layers (the first stage's conv2) through the resident-filter kernel
-    # (pe_conv3x3_c64_fwd_bf16) once the batch gives every CU several tiles; bit-identical to
-    # the engine.  PE_RESNET_PATCH3X3=0: the engine (comparison).
-    patch3x3 = os.environ.get("PE_RESNET_PATCH3X3", "1") != "0"
-
     def _conv(self, c: ConvSpec, x, residual=None, relu=None, **kw):
-        if (self.patch3x3 and c.k == 3 and c.stride == 1 and c.pad == 1 and c.cin == 64
-                and c.cout == 64 and residual is None and not kw
-                and x.shape[0] * ((x.shape[1] + 15) // 16) * ((x.shape[2] + 15) // 16) >= 1024):
-            return pnn.conv3x3_c64(x, self.w(c), self.scale[c.name], self.shift[c.name],
-                                   int(c.relu if relu is None else relu))
         return pnn.conv2d(x, self.w(c), self.scale[c.name], self.shift[c.name], residual,
                           c.stride, c.pad, c.relu if relu is None else relu, **kw)
 

@@ -92,6 +92,14 @@ def _check_act(x: torch.Tensor, name: str = "x"):
         raise ValueError(f"{name} must be a contiguous NHWC bfloat16 tensor")
 
 
+# 3x3 stride-1 pad-1 layers with 64 input and 64 output channels go through the resident-filter
+# kernel (pe_conv3x3_c64_fwd_bf16, bit-identical to the engine) once there are enough 16 x 16
+# tiles to give every CU several: one persistent workgroup per CU loads the 72 KB filter once.
+# PE_CONV_PATCH3X3=0: always the engine (comparison).
+PATCH3X3 = os.environ.get("PE_CONV_PATCH3X3", "1") != "0"
+PATCH3X3_MIN_TILES = 1024
+
+
 def conv2d(x: torch.Tensor, w: torch.Tensor, scale: Optional[torch.Tensor] = None,
            shift: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
            stride: int = 1, pad: int = 0, relu: bool = False, out_f32_nchw: bool = False,
@@ -114,6 +122,10 @@ def conv2d(x: torch.Tensor, w: torch.Tensor, scale: Optional[torch.Tensor] = Non
         raise ValueError("w must be contiguous bfloat16 [Cout,KH,KW,Cin]")
     Ho = (H + 2 * pad - KH) // stride + 1
     Wo = (W + 2 * pad - KW) // stride + 1
+    if (PATCH3X3 and Cin == 64 and Cout == 64 and KH == 3 and KW == 3 and stride == 1 and pad == 1
+            and residual is None and not out_f32_nchw
+            and B * ((H + 15) // 16) * ((W + 15) // 16) >= PATCH3X3_MIN_TILES):
+        return conv3x3_c64(x, w, scale, shift, int(relu), out)
     if out is None:
         if out_f32_nchw:
             out = torch.empty((B, Cout, Ho, Wo), dtype=torch.float32, device=x.device)

@@ -20,7 +20,11 @@ def main():
     path = sys.argv[1]
     batch = int(sys.argv[2]) if len(sys.argv) > 2 else 256
     tr = list(csv.DictReader(open(path)))
-    ig = [r for r in tr if "igemm" in r["Kernel_Name"]]
+    tr.sort(key=lambda r: int(r["Start_Timestamp"]))
+    # the launches that carry a layer: the engine, the stem + pool kernel (one launch for the
+    # stem) and the resident-filter 3x3 kernel
+    ig = [r for r in tr if any(k in r["Kernel_Name"] for k in
+                               ("igemm", "stem_pool_kernel", "conv3x3_c64_kernel"))]
     _, rows, _ = flops.forward_macs()
     macs = dict(rows)
     stem, blocks, deconvs, final = pm.resnet50_pose_specs()
@@ -36,9 +40,11 @@ def main():
         tot += dur
         tf = 2 * macs[name] * batch / (dur * 1e-6) / 1e12
         wgs = int(r["Grid_Size_X"]) // 256 * int(r["Grid_Size_Y"])
-        kern = r["Kernel_Name"].split("<")[1].split(">")[0]
+        kn = r["Kernel_Name"]
+        kern = kn.split("<")[1].split(">")[0] if "<" in kn else kn.split("(")[0].replace("pe::", "")
         print(f"{name:18s} tile {kern:8s} wgs {wgs:6d} {dur:8.1f} us {tf:7.1f} TF/s")
-    print(f"igemm total {tot:.1f} us")
+    print(f"layer kernels total {tot:.1f} us (the stem's row includes the max pool when the two are "
+          "one launch)")
 
 
 if __name__ == "__main__":

@@ -13,7 +13,7 @@ print("|---|---|---|---|---|---|---|---|")
 for f in sorted(glob.glob(os.path.join(sys.argv[1], "*.csv"))):
     acc = defaultdict(list)
     for r in csv.DictReader(open(f)):
-        if "igemm" in r["Kernel_Name"]:
+        if "igemm" in r["Kernel_Name"] or "conv3x3_c64" in r["Kernel_Name"]:
             acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
     m = {k: sum(v) / len(v) for k, v in acc.items()}
     n = len(acc["SQ_INSTS_MFMA"])

@@ -43,6 +43,19 @@ def main():
     for k in sorted(set(ffam) | set(wfam), key=lambda k: -(2 * ffam.get(k, 0) + wfam.get(k, 0)))[:14]:
         print(f"  {k[:44]:44s} read {2 * ffam.get(k, 0) * 1024 / 1e6:9.1f} MB   written "
               f"{wfam.get(k, 0) * 1024 / 1e6:9.1f} MB")
+    # the step's algorithmic bytes (every pass reads its operands and writes its result once)
+    sys.path.insert(0, str(ROOT))
+    alg, note = None, "per step, all kernels"
+    if name.startswith("resnet50_pose_train"):
+        from pose_estimation_amd import flops
+        alg = flops.train_step_bytes(64)[0]
+        note += "; algorithmic bytes = pose_estimation_amd.flops.train_step_bytes(64)"
+    elif name.startswith("hrnet_w32_pose_train"):
+        from pose_estimation_amd import hrnet
+        alg = hrnet.train_step_bytes(hrnet.hrnet_specs(), 64)[0]
+        note += "; algorithmic bytes = pose_estimation_amd.hrnet.train_step_bytes(spec, 64)"
+    if alg:
+        print(f"  algorithmic {alg / 1e9:.3f} GB -> traffic / algorithmic = {total / alg:.2f}")
     tfile = ROOT / "profiles" / "traffic.json"
     data = json.loads(tfile.read_text())
     data[name] = {
@@ -52,8 +65,8 @@ def main():
         "correction": "read bytes = 2 x FETCH_SIZE x 1024 (gfx950), written = WRITE_SIZE x 1024",
         "traffic_bytes_per_launch": total,
         "read_bytes": int(2 * f * 1024), "written_bytes": int(w * 1024),
-        "algorithmic_bytes_per_launch": None,
-        "note": "per step, all kernels; no algorithmic figure: the step is priced against the MFMA peak",
+        "algorithmic_bytes_per_launch": alg,
+        "note": note,
         "round": rnd,
     }
     tfile.write_text(json.dumps(data, indent=1) + "\n")
