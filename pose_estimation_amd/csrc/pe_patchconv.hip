@@ -156,37 +156,40 @@ __global__ __launch_bounds__(512, 1) void conv3x3_c64_kernel(const PatchConvPara
             for (int a = 0; a < 4; ++a)
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt) acc[a][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int tap = 0; tap < 9; ++tap) {
+            // 18 K steps (tap, 32-channel half).  The fragments of step s + 1 are requested
+            // before step s is multiplied, into the other of two register sets, so that with
+            // one multiplying wave per SIMD an LDS round trip hides behind 16 MFMAs instead
+            // of stalling them.
+            pc_bf16x8 af[2][4], bf[2][4];
+            auto load_step = [&](int s, pc_bf16x8(&fa)[4], pc_bf16x8(&fb)[4]) {
+                const int tap = s >> 1, kk = s & 1;
                 // byte offset of (pixel tile mt, tap) in the patch for the first 32-channel
-                // half (the second half is that offset ^ 64).  Recomputed per tap from a value
+                // half (the second half is that offset ^ 64).  Recomputed per step from a value
                 // the optimiser cannot see through: precomputed for all 36 (mt, tap) pairs
                 // they would sit in registers for the whole kernel and spill.
                 int lt = lr;
                 asm volatile("" : "+v"(lt));
-                int boff[4];
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+                    fa[a] = *reinterpret_cast<const pc_bf16x8*>(wl + tap * 8192 + a * 2048 +
+                                                                (aoff ^ (kk << 6)));
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt) {
                     const int pp = (cw * 4 + mt + tap / 3) * PC_P + lt + tap % 3;
-                    boff[mt] = pp * 128 + ((kc ^ (pp & 7)) << 4);
+                    const int boff = pp * 128 + ((kc ^ (pp & 7)) << 4);
+                    fb[mt] = *reinterpret_cast<const pc_bf16x8*>(xl + (boff ^ (kk << 6)));
                 }
+            };
+            load_step(0, af[0], bf[0]);
 #pragma unroll
-                for (int kk = 0; kk < 2; ++kk) {
-                    pc_bf16x8 af[4], bf[4];
+            for (int s = 0; s < 18; ++s) {
+                if (s + 1 < 18) load_step(s + 1, af[(s + 1) & 1], bf[(s + 1) & 1]);
 #pragma unroll
-                    for (int a = 0; a < 4; ++a)
-                        af[a] = *reinterpret_cast<const pc_bf16x8*>(wl + tap * 8192 + a * 2048 +
-                                                                    (aoff ^ (kk << 6)));
+                for (int a = 0; a < 4; ++a)
 #pragma unroll
                     for (int mt = 0; mt < 4; ++mt)
-                        bf[mt] = *reinterpret_cast<const pc_bf16x8*>(xl + (boff[mt] ^ (kk << 6)));
-#pragma unroll
-                    for (int a = 0; a < 4; ++a)
-#pragma unroll
-                        for (int mt = 0; mt < 4; ++mt)
-                            acc[a][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bf[mt],
-                                                                                 acc[a][mt], 0, 0, 0);
-                }
+                        acc[a][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                            af[s & 1][a], bf[s & 1][mt], acc[a][mt], 0, 0, 0);
             }
         }
         // every multiplying wave is done with this tile's patch: its output takes its place
