@@ -345,7 +345,9 @@ int32_t pe_stem7x7s2_pool_fwd_bf16(int32_t B, int32_t H2, int32_t W2, int32_t Co
  * pe_conv2d_fwd_bf16), x, y [B,H,W,64] bf16 NHWC, w [64][3][3][64] bf16: the 3x3 layers of the
  * first backbone stage (nets/mobilenet_v2.py, PoseEstimation.pyproj:32; absent) for inference.
  * One persistent workgroup per CU keeps the whole filter in LDS and stages each input patch
- * once instead of once per tap.  Equals pe_conv2d_fwd_bf16 on the same operands bit for bit. */
+ * once instead of once per tap; two groups of waves alternate between multiplying one tile and
+ * converting / storing the previous one.  H, W <= 8192 (PE_E_UNSUPPORTED beyond).  Equals
+ * pe_conv2d_fwd_bf16 on the same operands bit for bit. */
 int32_t pe_conv3x3_c64_fwd_bf16(int32_t B, int32_t H, int32_t W, const void* x, const void* w,
                                 const float* scale, const float* shift, int32_t relu, void* y,
                                 pe_stream_t stream);

@@ -5,14 +5,33 @@
 // times) for only 64 output channels and is bound by L2 -> LDS traffic, not by the matrix cores
 // (630 TFLOP/s at batch 256).  Here one persistent workgroup per CU keeps the WHOLE filter in
 // LDS (9 taps x 64 rows x 128 bytes = 72 KB, loaded once) and stages, per 16 x 16-pixel output
-// tile, the 18 x 18-pixel input patch ONCE (128 bytes per pixel, direct-to-LDS loads, the next
-// tile's patch in flight in a second buffer while the current one is multiplied); a tap is an
-// address offset into the patch.  Staged bytes per output tile fall from 360 KB to 41 KB.
+// tile, the 18 x 18-pixel input patch ONCE (128 bytes per pixel, direct-to-LDS loads); a tap is
+// an address offset into the patch.  Staged bytes per output tile fall from 360 KB to 41 KB.
+//
+// Two groups of waves in opposite phases.  All eight waves multiply: group g (waves 4g .. 4g+3,
+// one per SIMD) owns patch buffer g and every second tile of the workgroup.  Time is cut into
+// phases by workgroup barriers; in phase f group (f & 1) multiplies tile f from its buffer while
+// the other group finishes tile f - 1: it requests the patch of tile f + 1 into its own buffer
+// (free since the barrier: its reads ended with its multiply), then converts its accumulators
+// and stores them straight from registers.  A SIMD therefore always holds one wave that
+// multiplies and one that converts, stores and requests, and the matrix cores do not wait for
+// an epilogue.  (With four multiplying waves that all converted at the same barrier, and four
+// helper waves moving data, the same layer took 82 us; this form 56-60 us; the multiplies alone
+// 38 us.)
+//
+// No LDS staging of the output: a lane's four accumulators of (channel tile a, pixel tile mt)
+// are channels 16 a + 4 kc .. + 3 of pixel 16 mt + lr (kc = lane >> 4).  Packed to bf16 they
+// are 8 bytes; v_permlane16_swap_b32 exchanges the odd 16-lane rows of one register with the
+// even rows of another, which, applied to the packed values of channel tiles a and a + 1, hands
+// every lane 16 contiguous bytes: rows 0 / 2 channels 16 a + {0..7, 8..15}, rows 1 / 3 the same
+// of tile a + 1.  One store instruction then writes 64 contiguous bytes of each of 16 pixels.
 //
 // Layout: a patch pixel is one 128-byte LDS row of 8 x 16-byte slots, slot s holding channel
-// chunk s ^ (pixel index & 7); the 16 lanes of an MFMA B-fragment read 16 consecutive pixels of
-// a patch row, hence 16 distinct (pixel & 7, chunk) combinations per 8: conflict-free, as in the
-// engine's tiles.  The filter planes use the engine's weight-tile layout.
+// chunk s ^ (patch column & 7).  The 16-lane groups of a ds_read_b128 read consecutive pixels
+// of one patch row (rows are 18 pixels, an even count, so pixel parity = column parity), which
+// makes (pixel parity, slot) distinct inside a group: conflict-free, as in the engine's tiles,
+// and a tap's row offset becomes a compile-time constant.  The filter planes use the engine's
+// weight-tile layout.
 //
 // MFMA operand roles, K order (tap by tap, two 32-channel halves each) and the epilogue's
 // operations are those of the engine, so the result equals pe_conv2d_fwd_bf16 bit for bit.
@@ -55,69 +74,46 @@ __device__ __forceinline__ PcTile pc_tile(const PatchConvParams& p, int t) {
     return PcTile{r / p.tiles_y, (r % p.tiles_y) * PC_T, tx0 * PC_T};
 }
 
-// Helper wave `hw` (0..3) requests its share of the 18 x 18 patch of tile `t` into `buf`
-// (direct-to-LDS, asynchronous): the 1 KB blocks j = hw, hw + 4, ... of the buffer.
-__device__ __forceinline__ void pc_issue_patch(const PatchConvParams& p, int t, char* buf, int hw,
-                                               int lane) {
-    if (t >= p.ntiles) return;                    // uniform
-    const PcTile tl = pc_tile(p, t);
-    const int sy0 = tl.y0 - 1, sx0 = tl.x0 - 1;
-    const uint16_t* img = p.x + (long)tl.b * p.H * p.W * 64;
-    const uint16_t* zero = reinterpret_cast<const uint16_t*>(g_pc_zero16);
-#pragma unroll
-    for (int i = 0; i < (PC_NINSTR + 3) / 4; ++i) {
-        const int j = i * 4 + hw;                 // this wave's block: 8 patch pixels
-        if (j >= PC_NINSTR) break;                // uniform
-        const int pp = j * 8 + (lane >> 3);
-        const int py = pp / PC_P, px = pp - py * PC_P;
-        const int sy = sy0 + py, sx = sx0 + px;
-        const int cc = (lane & 7) ^ (pp & 7);
-        const bool ok = pp < PC_NPIX && (unsigned)sy < (unsigned)p.H && (unsigned)sx < (unsigned)p.W;
-        const uint16_t* src = ok ? img + ((long)sy * p.W + sx) * 64 + cc * 8 : zero;
-        __builtin_amdgcn_global_load_lds((pc_gptr_t)src, (pc_lptr_t)(buf + j * 1024), 16, 0, 0);
+__device__ __forceinline__ uint32_t pc_act_pack(float v0, float v1, float s0, float s1, float h0,
+                                                float h1, const bool affine, const int relu) {
+    if (affine) {
+        v0 = fmaf(v0, s0, h0);
+        v1 = fmaf(v1, s1, h1);
     }
-}
-
-// Helper wave `hw` writes its share of the finished output tile in `buf` to memory: the rows
-// of blocks j = hw, hw + 4, ..., hw + 28, i.e. exactly the LDS bytes its own next patch requests
-// overwrite, so the wave's own lgkmcnt orders the two and no barrier between helpers is needed.
-__device__ __forceinline__ void pc_store_tile(const PatchConvParams& p, const PcTile& tl,
-                                              const char* buf, int hw, int lane) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int m = (i * 4 + hw) * 8 + (lane >> 3), ch = lane & 7;
-        const int oy = tl.y0 + (m >> 4), ox = tl.x0 + (m & 15);
-        if (oy < p.H && ox < p.W) {
-            const uint4 v = *reinterpret_cast<const uint4*>(buf + m * 128 + ((ch ^ (m & 7)) << 4));
-            *reinterpret_cast<uint4*>(p.y + (((long)tl.b * p.H + oy) * p.W + ox) * 64 + ch * 8) = v;
+    if (relu) {
+        v0 = fmaxf(v0, 0.0f);
+        v1 = fmaxf(v1, 0.0f);
+        if (relu == 2) {
+            v0 = fminf(v0, 6.0f);
+            v1 = fminf(v1, 6.0f);
         }
     }
+    return pack_bf16x2_bits(v0, v1);
 }
 
-// 512 threads: waves 0-3 multiply and convert, waves 4-7 ("helpers", one per SIMD beside a
-// multiplying wave) move data: they write the previous tile's output rows to memory and request
-// the next tile's patch while the current tile is multiplied.  Alone on its SIMD a multiplying
-// wave would do all of that itself, in sequence (measured: multiply 45 us, convert 16, store 13,
-// requests and waits 27 of a 100 us launch); the helpers take the last two off its path.
+typedef unsigned pc_u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned pc_u32x4 __attribute__((ext_vector_type(4)));
+
+template <int RELU, bool AFFINE>
 __global__ __launch_bounds__(512, 1) void conv3x3_c64_kernel(const PatchConvParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* wl = smem;
-    char* const xb0 = smem + PC_WBYTES;                   // two patch buffers
+    char* const xb0 = smem + PC_WBYTES;
     float* ssl = reinterpret_cast<float*>(smem + PC_WBYTES + 2 * PC_XBYTES);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);   // 0..7
-    const bool helper = wid >= 4;
-    const int cw = wid & 3;                               // index among the multiplying / helper waves
+    const int g = wid >> 2;                               // group: 0 or 1
+    const int cw = wid & 3;                               // wave inside the group
     const int lr = lane & 15, kc = lane >> 4;
+    char* const xl = xb0 + g * PC_XBYTES;                 // this group's patch buffer
 
-    // ---- filter: 9 x 64 rows of 128 bytes; lane l of a wave instruction -> row l>>3, slot l&7
     {
         const int cc = (lane & 7) ^ ((lane >> 3) & 7);
 #pragma unroll
         for (int i = 0; i < 9; ++i) {
-            const int R = i * 64 + (tid >> 3);            // tap * 64 + output channel
+            const int R = i * 64 + (tid >> 3);
             const uint16_t* src = p.w + (long)(R & 63) * 576 + (R >> 6) * 64 + cc * 8;
             __builtin_amdgcn_global_load_lds((pc_gptr_t)src,
                                              (pc_lptr_t)(wl + (i * 64 + 8 * wid) * 128), 16, 0, 0);
@@ -127,117 +123,166 @@ __global__ __launch_bounds__(512, 1) void conv3x3_c64_kernel(const PatchConvPara
         ssl[tid] = p.scale ? p.scale[tid] : 1.0f;
         ssl[64 + tid] = p.shift ? p.shift[tid] : 0.0f;
     }
-    const bool affine = p.scale != nullptr || p.shift != nullptr;
-    if (helper) pc_issue_patch(p, blockIdx.x, xb0, cw, lane);
+    // tiles of this workgroup: blockIdx.x + k * gridDim.x, k = 0 .. n - 1; group g takes k = g mod 2
+    const int n = (p.ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    // Patch requests of this wave: blocks j = cw, cw + 4, ... of 8 pixels.  What depends on the
+    // lane alone (its pixel's row and column in the patch, its byte offset from the patch
+    // origin) is worked out once; per tile a request costs two compares and a select.
+    constexpr int NB = (PC_NINSTR + 3) / 4;               // 11
+    int prel[NB], pyx[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const int pp = (i * 4 + cw) * 8 + (lane >> 3);
+        const int py = pp / PC_P, px = pp - py * PC_P;
+        const int cc = (lane & 7) ^ (px & 7);
+        prel[i] = (py * p.W + px) * 128 + cc * 16;
+        pyx[i] = pp < PC_NPIX ? (py | (px << 16)) : 0x4000;   // a row no image has
+    }
+    const char* const zero = reinterpret_cast<const char*>(g_pc_zero16);
+    auto issue_patch = [&](int t) {
+        if (t >= p.ntiles) return;                        // uniform
+        const PcTile tl = pc_tile(p, t);
+        const int sy0 = tl.y0 - 1, sx0 = tl.x0 - 1;
+        const char* origin = reinterpret_cast<const char*>(p.x) +
+                             (((long)tl.b * p.H + sy0) * p.W + sx0) * 128;
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            if (i * 4 + cw >= PC_NINSTR) break;           // uniform
+            const bool ok = (unsigned)(sy0 + (pyx[i] & 0xffff)) < (unsigned)p.H &&
+                            (unsigned)(sx0 + (pyx[i] >> 16)) < (unsigned)p.W;
+            const char* src = ok ? origin + prel[i] : zero;
+            __builtin_amdgcn_global_load_lds((pc_gptr_t)src, (pc_lptr_t)(xl + (i * 4 + cw) * 1024),
+                                             16, 0, 0);
+        }
+    };
+    issue_patch(blockIdx.x + g * gridDim.x);              // tile k = g (or none)
 
+    // Fragment addresses, all of the per-lane part worked out once: a K step then issues its 8
+    // LDS reads with immediate offsets and no vector arithmetic (one wave per SIMD multiplies,
+    // and a wave issues at most one instruction every four cycles, so every address
+    // instruction in the loop displaces an MFMA).  The patch's slot swizzle goes by the pixel's
+    // COLUMN (rows are 18 pixels = an even count, which keeps reads conflict-free), so that a
+    // tap's row offset is a constant.
     const int aoff = lr * 128 + ((kc ^ (lr & 7)) << 4);
-    const int nq = kc * 4;
+    const uint32_t lds_w = (uint32_t)(uintptr_t)(pc_lptr_t)wl;     // LDS byte addresses
+    const uint32_t lds_x = (uint32_t)(uintptr_t)(pc_lptr_t)xl;
+    uint32_t abase[2], abase_hi[2], bbase[3][2];
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        abase[kk] = lds_w + (aoff ^ (kk << 6));
+        abase_hi[kk] = abase[kk] + 65536;           // the last tap lies past the 16-bit offset field
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx)
+            bbase[dx][kk] = lds_x + (((cw * 4 * PC_P + lr + dx) * 128 +
+                                      ((kc ^ ((lr + dx) & 7)) << 4)) ^ (kk << 6));
+    }
 
-    // the filter and the first patch have landed
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 
-    int cur = 0;
-    PcTile prev{0, 0, 0};
-    bool have_prev = false;
-    for (int t = blockIdx.x; t < p.ntiles; t += gridDim.x, cur ^= 1) {
-        char* xl = xb0 + cur * PC_XBYTES;
-        char* xo = xb0 + (cur ^ 1) * PC_XBYTES;
-        f32x4 acc[4][4];
-        if (helper) {
-            // the other buffer holds the previous tile's output: out to memory, then the next
-            // tile's patch over it
-            if (have_prev) pc_store_tile(p, prev, xo, cw, lane);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            pc_issue_patch(p, t + gridDim.x, xo, cw, lane);
-        } else {
-#pragma unroll
-            for (int a = 0; a < 4; ++a)
-#pragma unroll
-                for (int mt = 0; mt < 4; ++mt) acc[a][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-            // 18 K steps (tap, 32-channel half).  The fragments of step s + 1 are requested
-            // before step s is multiplied, into the other of two register sets, so that with
-            // one multiplying wave per SIMD an LDS round trip hides behind 16 MFMAs instead
-            // of stalling them.
-            pc_bf16x8 af[2][4], bf[2][4];
-            auto load_step = [&](int s, pc_bf16x8(&fa)[4], pc_bf16x8(&fb)[4]) {
-                const int tap = s >> 1, kk = s & 1;
-                // byte offset of (pixel tile mt, tap) in the patch for the first 32-channel
-                // half (the second half is that offset ^ 64).  Recomputed per step from a value
-                // the optimiser cannot see through: precomputed for all 36 (mt, tap) pairs
-                // they would sit in registers for the whole kernel and spill.
-                int lt = lr;
-                asm volatile("" : "+v"(lt));
+    f32x4 acc[4][4];
+    for (int f = 0; f <= n; ++f) {
+        if (((f ^ g) & 1) == 0) {
+            // ---- multiply tile f (if there is one)
+            if (f < n) {
 #pragma unroll
                 for (int a = 0; a < 4; ++a)
-                    fa[a] = *reinterpret_cast<const pc_bf16x8*>(wl + tap * 8192 + a * 2048 +
-                                                                (aoff ^ (kk << 6)));
 #pragma unroll
-                for (int mt = 0; mt < 4; ++mt) {
-                    const int pp = (cw * 4 + mt + tap / 3) * PC_P + lt + tap % 3;
-                    const int boff = pp * 128 + ((kc ^ (pp & 7)) << 4);
-                    fb[mt] = *reinterpret_cast<const pc_bf16x8*>(xl + (boff ^ (kk << 6)));
-                }
-            };
-            load_step(0, af[0], bf[0]);
+                    for (int mt = 0; mt < 4; ++mt) acc[a][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                // The 8 fragment reads of K step s + 1 are issued before step s is multiplied
+                // and step s waits with a COUNTED lgkmcnt(8): LDS reads return in order, so
+                // "all but the 8 youngest" is exactly step s.  The reads and the waits are
+                // inline assembly because the compiler, left to schedule them, sinks every read
+                // down to its first use and waits for an empty queue (one exposed LDS round
+                // trip per 8 MFMAs: measured 55 % of the register-only MFMA rate).  A wait
+                // names the registers it guards as operands, so no MFMA can move above it.
+                pc_u32x4 fa[2][4], fb[2][4];
+                auto load_step = [&](int s, pc_u32x4(&qa)[4], pc_u32x4(&qb)[4]) {
+                    const int tap = s >> 1, kk = s & 1;
 #pragma unroll
-            for (int s = 0; s < 18; ++s) {
-                if (s + 1 < 18) load_step(s + 1, af[(s + 1) & 1], bf[(s + 1) & 1]);
-#pragma unroll
-                for (int a = 0; a < 4; ++a)
+                    for (int a = 0; a < 4; ++a) {
+                        const int off = tap * 8192 + a * 2048;
+                        if (off < 65536)
+                            asm volatile("ds_read_b128 %0, %1 offset:%2"
+                                         : "=v"(qa[a]) : "v"(abase[kk]), "n"(off < 65536 ? off : 0));
+                        else
+                            asm volatile("ds_read_b128 %0, %1 offset:%2"
+                                         : "=v"(qa[a]) : "v"(abase_hi[kk]), "n"(off >= 65536 ? off - 65536 : 0));
+                    }
 #pragma unroll
                     for (int mt = 0; mt < 4; ++mt)
-                        acc[a][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                            af[s & 1][a], bf[s & 1][mt], acc[a][mt], 0, 0, 0);
-            }
-        }
-        // every multiplying wave is done with this tile's patch: its output takes its place
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if (helper) {
-            // the next patch has landed (and the stores are out) before the tile is handed over
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        } else {
+                        asm volatile("ds_read_b128 %0, %1 offset:%2"
+                                     : "=v"(qb[mt])
+                                     : "v"(bbase[tap % 3][kk]), "n"((mt + tap / 3) * (PC_P * 128)));
+                };
+                load_step(0, fa[0], fb[0]);
 #pragma unroll
-            for (int a = 0; a < 4; ++a) {
-                const int n = a * 16 + nq;
-                const f32x4 sc = *reinterpret_cast<const f32x4*>(ssl + n);
-                const f32x4 sh = *reinterpret_cast<const f32x4*>(ssl + 64 + n);
+                for (int s = 0; s < 18; ++s) {
+                    pc_u32x4(&qa)[4] = fa[s & 1];
+                    pc_u32x4(&qb)[4] = fb[s & 1];
+                    if (s + 1 < 18) {
+                        load_step(s + 1, fa[(s + 1) & 1], fb[(s + 1) & 1]);
+                        asm volatile("s_waitcnt lgkmcnt(8)"
+                                     : "+v"(qa[0]), "+v"(qa[1]), "+v"(qa[2]), "+v"(qa[3]),
+                                       "+v"(qb[0]), "+v"(qb[1]), "+v"(qb[2]), "+v"(qb[3]));
+                    } else {
+                        asm volatile("s_waitcnt lgkmcnt(0)"
+                                     : "+v"(qa[0]), "+v"(qa[1]), "+v"(qa[2]), "+v"(qa[3]),
+                                       "+v"(qb[0]), "+v"(qb[1]), "+v"(qb[2]), "+v"(qb[3]));
+                    }
 #pragma unroll
-                for (int mt = 0; mt < 4; ++mt) {
-                    const int m = (cw * 4 + mt) * 16 + lr;
-                    float v0 = acc[a][mt].x, v1 = acc[a][mt].y, v2 = acc[a][mt].z, v3 = acc[a][mt].w;
-                    if (affine) {
-                        v0 = fmaf(v0, sc.x, sh.x);
-                        v1 = fmaf(v1, sc.y, sh.y);
-                        v2 = fmaf(v2, sc.z, sh.z);
-                        v3 = fmaf(v3, sc.w, sh.w);
-                    }
-                    if (p.relu) {
-                        v0 = fmaxf(v0, 0.0f); v1 = fmaxf(v1, 0.0f);
-                        v2 = fmaxf(v2, 0.0f); v3 = fmaxf(v3, 0.0f);
-                        if (p.relu == 2) {
-                            v0 = fminf(v0, 6.0f); v1 = fminf(v1, 6.0f);
-                            v2 = fminf(v2, 6.0f); v3 = fminf(v3, 6.0f);
-                        }
-                    }
-                    uint2 o;
-                    o.x = pack_bf16x2_bits(v0, v1);
-                    o.y = pack_bf16x2_bits(v2, v3);
-                    *reinterpret_cast<uint2*>(xl + m * 128 + ((((n >> 3) ^ (m & 7)) << 4) | ((n & 7) << 1))) = o;
+                    for (int a = 0; a < 4; ++a)
+#pragma unroll
+                        for (int mt = 0; mt < 4; ++mt)
+                            acc[a][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                                __builtin_bit_cast(pc_bf16x8, qa[a]),
+                                __builtin_bit_cast(pc_bf16x8, qb[mt]), acc[a][mt], 0, 0, 0);
                 }
             }
+            // every read of the patch has returned before the barrier frees the buffer
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        } else if (f >= 1) {
+            // ---- finish tile f - 1: next patch first (the loads fly under the conversion)
+            issue_patch(blockIdx.x + (f + 1) * gridDim.x);
+            const PcTile tl = pc_tile(p, blockIdx.x + (f - 1) * gridDim.x);
+            // lane's 16 bytes of a pixel: rows 0 / 2 belong to the even channel tile of a pair
+            const int chb = ((kc & 1) * 32) + ((kc >> 1) * 16);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {                 // channel-tile pairs (0, 1), (2, 3)
+                const int n0 = (2 * j) * 16 + kc * 4, n1 = n0 + 16;
+                const f32x4 sc0 = *reinterpret_cast<const f32x4*>(ssl + n0);
+                const f32x4 sh0 = *reinterpret_cast<const f32x4*>(ssl + 64 + n0);
+                const f32x4 sc1 = *reinterpret_cast<const f32x4*>(ssl + n1);
+                const f32x4 sh1 = *reinterpret_cast<const f32x4*>(ssl + 64 + n1);
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) {
+                    const f32x4 c0 = acc[2 * j][mt], c1 = acc[2 * j + 1][mt];
+                    const uint32_t x0 = pc_act_pack(c0.x, c0.y, sc0.x, sc0.y, sh0.x, sh0.y, AFFINE, RELU);
+                    const uint32_t x1 = pc_act_pack(c0.z, c0.w, sc0.z, sc0.w, sh0.z, sh0.w, AFFINE, RELU);
+                    const uint32_t y0 = pc_act_pack(c1.x, c1.y, sc1.x, sc1.y, sh1.x, sh1.y, AFFINE, RELU);
+                    const uint32_t y1 = pc_act_pack(c1.z, c1.w, sc1.z, sc1.w, sh1.z, sh1.w, AFFINE, RELU);
+                    // odd rows of x <-> even rows of y
+                    const pc_u32x2 s0 = __builtin_amdgcn_permlane16_swap(x0, y0, false, false);
+                    const pc_u32x2 s1 = __builtin_amdgcn_permlane16_swap(x1, y1, false, false);
+                    const uint4 o = make_uint4(s0.x, s1.x, s0.y, s1.y);
+                    const int oy = tl.y0 + cw * 4 + mt, ox = tl.x0 + lr;
+                    if (oy < p.H && ox < p.W)
+                        *reinterpret_cast<uint4*>(reinterpret_cast<char*>(p.y) +
+                                                  ((((long)tl.b * p.H + oy) * p.W + ox) * 128 +
+                                                   j * 64 + chb)) = o;
+                }
+            }
+            // The patch requests are older than the 8 stores, and vector memory operations
+            // retire in order: a tile that lies wholly inside the image issued all 8 stores,
+            // so "all but 8" means the patch has landed; an edge tile may have skipped some.
+            const bool full = tl.y0 + PC_T <= p.H && tl.x0 + PC_T <= p.W;
+            if (full) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        prev = pc_tile(p, t);
-        have_prev = true;
     }
-    // the last tile's output sits in the buffer the loop used last
-    if (helper && have_prev) pc_store_tile(p, prev, xb0 + (cur ^ 1) * PC_XBYTES, cw, lane);
 }
 
 }  // namespace pe
@@ -250,6 +295,7 @@ extern "C" int32_t pe_conv3x3_c64_fwd_bf16(int32_t B, int32_t H, int32_t W, cons
     const char* what = "pe_conv3x3_c64_fwd_bf16";
     PE_REQUIRE(x && w && y, PE_E_INVALID, "%s: NULL pointer", what);
     PE_REQUIRE(B > 0 && H > 0 && W > 0, PE_E_INVALID, "%s: sizes must be positive", what);
+    PE_REQUIRE(H <= 8192 && W <= 8192, PE_E_UNSUPPORTED, "%s: images above 8192 x 8192", what);
     PE_REQUIRE(relu >= 0 && relu <= 2, PE_E_INVALID, "%s: relu must be 0, 1 or 2", what);
     PE_REQUIRE(aligned(x, 16) && aligned(w, 16) && aligned(y, 16) && aligned(scale, 16) &&
                    aligned(shift, 16),
@@ -273,8 +319,18 @@ extern "C" int32_t pe_conv3x3_c64_fwd_bf16(int32_t B, int32_t H, int32_t W, cons
     if (hipGetDevice(&dev) == hipSuccess)
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     const long nwg = ntiles < cus ? ntiles : cus;   // one persistent workgroup per CU (154 KB of LDS)
-    const hipError_t e = pe::ensure_dynamic_lds<&conv3x3_c64_kernel>(PC_LDS);
+    const bool affine = scale != nullptr || shift != nullptr;
+    hipError_t e = hipSuccess;
+#define PC_CASE(R, A)                                                                           \
+    if (relu == R && affine == A) {                                                             \
+        e = pe::ensure_dynamic_lds<&conv3x3_c64_kernel<R, A>>(PC_LDS);                       \
+        if (e == hipSuccess)                                                                    \
+            pe::launch(conv3x3_c64_kernel<R, A>, (unsigned)nwg, 512, (size_t)PC_LDS,         \
+                       as_stream(stream), p);                                                   \
+    }
+    PC_CASE(0, false) PC_CASE(1, false) PC_CASE(2, false)
+    PC_CASE(0, true) PC_CASE(1, true) PC_CASE(2, true)
+#undef PC_CASE
     PE_REQUIRE(e == hipSuccess, PE_E_HIP, "%s: LDS opt-in: %s", what, hipGetErrorString(e));
-    pe::launch(conv3x3_c64_kernel, (unsigned)nwg, 512, (size_t)PC_LDS, as_stream(stream), p);
     return check_launch(what);
 }
