@@ -352,6 +352,22 @@ int32_t pe_conv3x3_c64_fwd_bf16(int32_t B, int32_t H, int32_t W, const void* x, 
                                 const float* scale, const float* shift, int32_t relu, void* y,
                                 pe_stream_t stream);
 
+/* The same 3x3 layer followed, in the same launch, by the pointwise (1x1) layer that reads it:
+ * y = act3( conv1x1( bf16( act(conv3x3(x, w) * scale + shift) ), w3 ) * scale3 + shift3 + residual ),
+ * w3 [Cout3][64] bf16, scale3 / shift3 [Cout3] float32 (NULL = 1 / 0), residual and y
+ * [B,H,W,Cout3] bf16, relu3 0 or 1: conv2 and conv3 of a bottleneck of the first backbone
+ * stage (nets/mobilenet_v2.py, PoseEstimation.pyproj:32; absent).  The 64-channel tensor between
+ * the two layers is never written: a finished tile stays in registers, rounded to bf16 exactly
+ * as the separate launch would store it, and is the activation operand of the 1x1 layer.
+ * Cout3 must be 256, scale / shift must be given (folded batch norm) and relu must be 1
+ * (PE_E_UNSUPPORTED otherwise).  Equals pe_conv2d_fwd_bf16(1x1, residual, relu3) of
+ * pe_conv3x3_c64_fwd_bf16 bit for bit. */
+int32_t pe_conv3x3_c64_pw_fwd_bf16(int32_t B, int32_t H, int32_t W, const void* x, const void* w,
+                                   const float* scale, const float* shift, int32_t relu,
+                                   const void* w3, int32_t Cout3, const float* scale3,
+                                   const float* shift3, const void* residual, int32_t relu3,
+                                   void* y, pe_stream_t stream);
+
 /* 3x3 stride-2 pad-1 stem on a 3-channel image (MobileNetV2's first conv; the reference's
  * backbone, nets/mobilenet_v2.py, PoseEstimation.pyproj:32, absent), computed over the same
  * space-to-depth image as a 2-row conv: w [Cout][2 rows][4 cols x 16] bf16 (columns 2, 3 zero),

@@ -40,38 +40,60 @@
 namespace pe {
 
 typedef __bf16 pc_bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned pc_u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned pc_u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(1))) const void* pc_gptr_t;
 typedef __attribute__((address_space(3))) void* pc_lptr_t;
 
-constexpr int PC_T = 16;                          // output tile edge
-constexpr int PC_P = PC_T + 2;                    // patch edge
-constexpr int PC_NPIX = PC_P * PC_P;              // 324 patch pixels
-constexpr int PC_NINSTR = (PC_NPIX + 7) / 8;      // 41 wave instructions of 8 pixels
-constexpr int PC_WBYTES = 9 * 64 * 128;           // 73 728
-constexpr int PC_XBYTES = PC_NINSTR * 1024;       // 41 984 per patch buffer
-constexpr int PC_LDS = PC_WBYTES + 2 * PC_XBYTES + 2 * 64 * 4;
+constexpr int PC_TX = 16;                         // output tile width
+constexpr int PC_P = PC_TX + 2;                   // patch width
+constexpr int PC_WBYTES = 9 * 64 * 128;           // 73 728: the 3x3 filter
+constexpr int PC_N3 = 256;                        // output channels of the fused pointwise layer
+constexpr int PC_W3BYTES = PC_N3 * 128;           // 32 768: its weights
+
+// Geometry of a variant.  Alone, the 3x3 layer works on 16 x 16 tiles (4 rows per wave).  With
+// the pointwise layer the tile is 8 rows high (2 rows per wave): its smaller patch buffers make
+// room for the pointwise weights in LDS, and a wave's share of the 256-channel output (32 pixels)
+// leaves registers for residual loads several chunks ahead.
+template <int PW>
+struct PcGeo {
+    static constexpr int TY = PW ? 8 : 16;            // output tile height
+    static constexpr int MT = TY / 4;                 // 16-pixel rows per wave
+    static constexpr int NPIX = (TY + 2) * PC_P;      // patch pixels: 324 / 180
+    static constexpr int NINSTR = (NPIX + 7) / 8;     // wave instructions of 8 pixels: 41 / 23
+    static constexpr int XBYTES = NINSTR * 1024;      // per patch buffer: 41 984 / 23 552
+    static constexpr int W3B = PW ? PC_W3BYTES : 0;
+    static constexpr int LDS = PC_WBYTES + W3B + 2 * XBYTES + 2 * 64 * 4 + (PW ? 2 * PC_N3 * 4 : 0);
+};
 
 __device__ __attribute__((aligned(16))) uint32_t g_pc_zero16[4] = {0u, 0u, 0u, 0u};
+// where the lanes of pixels outside the image store (never read): lets every store of the fused
+// kernel be unconditional, so that the compiler can count the operations in flight
+__device__ __attribute__((aligned(16))) uint32_t g_pc_sink[512];
 
 struct PatchConvParams {
     const uint16_t* x;     // [B][H][W][64]
     const uint16_t* w;     // [64][3][3][64]
     const float* scale;
     const float* shift;
-    uint16_t* y;           // [B][H][W][64]
+    uint16_t* y;           // [B][H][W][64], or [B][H][W][256] with the pointwise layer
+    const uint16_t* w3;    // pointwise layer: [256][64], its scale / shift [256] and the
+    const float* scale3;   // residual [B][H][W][256] added before its ReLU
+    const float* shift3;
+    const uint16_t* res;
     int B, H, W;
     int tiles_x, tiles_y, ntiles;
-    int relu;
 };
 
 struct PcTile {
     int b, y0, x0;
 };
 
+template <int TY>
 __device__ __forceinline__ PcTile pc_tile(const PatchConvParams& p, int t) {
     const int tx0 = t % p.tiles_x;
     const int r = t / p.tiles_x;
-    return PcTile{r / p.tiles_y, (r % p.tiles_y) * PC_T, tx0 * PC_T};
+    return PcTile{r / p.tiles_y, (r % p.tiles_y) * TY, tx0 * PC_TX};
 }
 
 __device__ __forceinline__ uint32_t pc_act_pack(float v0, float v1, float s0, float s1, float h0,
@@ -91,15 +113,16 @@ __device__ __forceinline__ uint32_t pc_act_pack(float v0, float v1, float s0, fl
     return pack_bf16x2_bits(v0, v1);
 }
 
-typedef unsigned pc_u32x2 __attribute__((ext_vector_type(2)));
-typedef unsigned pc_u32x4 __attribute__((ext_vector_type(4)));
-
-template <int RELU, bool AFFINE>
+template <int RELU, bool AFFINE, int PW>
 __global__ __launch_bounds__(512, 1) void conv3x3_c64_kernel(const PatchConvParams p) {
+    using G = PcGeo<PW>;
+    constexpr int MT = G::MT;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* wl = smem;
-    char* const xb0 = smem + PC_WBYTES;
-    float* ssl = reinterpret_cast<float*>(smem + PC_WBYTES + 2 * PC_XBYTES);
+    char* wl = smem;                                      // 3x3 filter
+    char* w3l = smem + PC_WBYTES;                         // pointwise weights (PW only)
+    char* const xb0 = smem + PC_WBYTES + G::W3B;          // two patch buffers
+    float* ssl = reinterpret_cast<float*>(xb0 + 2 * G::XBYTES);
+    float* ssl3 = ssl + 128;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -107,28 +130,44 @@ __global__ __launch_bounds__(512, 1) void conv3x3_c64_kernel(const PatchConvPara
     const int g = wid >> 2;                               // group: 0 or 1
     const int cw = wid & 3;                               // wave inside the group
     const int lr = lane & 15, kc = lane >> 4;
-    char* const xl = xb0 + g * PC_XBYTES;                 // this group's patch buffer
+    char* const xl = xb0 + g * G::XBYTES;                 // this group's patch buffer
 
+    // ---- weights: rows of 128 bytes; lane l of a wave instruction -> row l>>3, slot l&7, which
+    // receives channel chunk (l & 7) ^ (row & 7)
     {
         const int cc = (lane & 7) ^ ((lane >> 3) & 7);
 #pragma unroll
         for (int i = 0; i < 9; ++i) {
-            const int R = i * 64 + (tid >> 3);
+            const int R = i * 64 + (tid >> 3);            // tap * 64 + output channel
             const uint16_t* src = p.w + (long)(R & 63) * 576 + (R >> 6) * 64 + cc * 8;
             __builtin_amdgcn_global_load_lds((pc_gptr_t)src,
                                              (pc_lptr_t)(wl + (i * 64 + 8 * wid) * 128), 16, 0, 0);
+        }
+        if constexpr (PW != 0) {
+#pragma unroll
+            for (int i = 0; i < PC_N3 / 64; ++i) {
+                const int R = i * 64 + (tid >> 3);        // output channel of the pointwise layer
+                const uint16_t* src = p.w3 + (long)R * 64 + cc * 8;
+                __builtin_amdgcn_global_load_lds(
+                    (pc_gptr_t)src, (pc_lptr_t)(w3l + (i * 64 + 8 * wid) * 128), 16, 0, 0);
+            }
         }
     }
     if (tid < 64) {
         ssl[tid] = p.scale ? p.scale[tid] : 1.0f;
         ssl[64 + tid] = p.shift ? p.shift[tid] : 0.0f;
     }
+    if (PW && tid < PC_N3) {
+        ssl3[tid] = p.scale3 ? p.scale3[tid] : 1.0f;
+        ssl3[PC_N3 + tid] = p.shift3 ? p.shift3[tid] : 0.0f;
+    }
     // tiles of this workgroup: blockIdx.x + k * gridDim.x, k = 0 .. n - 1; group g takes k = g mod 2
     const int n = (p.ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+
     // Patch requests of this wave: blocks j = cw, cw + 4, ... of 8 pixels.  What depends on the
     // lane alone (its pixel's row and column in the patch, its byte offset from the patch
     // origin) is worked out once; per tile a request costs two compares and a select.
-    constexpr int NB = (PC_NINSTR + 3) / 4;               // 11
+    constexpr int NB = (G::NINSTR + 3) / 4;               // 11 / 6
     int prel[NB], pyx[NB];
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
@@ -136,18 +175,18 @@ __global__ __launch_bounds__(512, 1) void conv3x3_c64_kernel(const PatchConvPara
         const int py = pp / PC_P, px = pp - py * PC_P;
         const int cc = (lane & 7) ^ (px & 7);
         prel[i] = (py * p.W + px) * 128 + cc * 16;
-        pyx[i] = pp < PC_NPIX ? (py | (px << 16)) : 0x4000;   // a row no image has
+        pyx[i] = pp < G::NPIX ? (py | (px << 16)) : 0x4000;   // a row no image has
     }
     const char* const zero = reinterpret_cast<const char*>(g_pc_zero16);
     auto issue_patch = [&](int t) {
         if (t >= p.ntiles) return;                        // uniform
-        const PcTile tl = pc_tile(p, t);
+        const PcTile tl = pc_tile<G::TY>(p, t);
         const int sy0 = tl.y0 - 1, sx0 = tl.x0 - 1;
         const char* origin = reinterpret_cast<const char*>(p.x) +
                              (((long)tl.b * p.H + sy0) * p.W + sx0) * 128;
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
-            if (i * 4 + cw >= PC_NINSTR) break;           // uniform
+            if (i * 4 + cw >= G::NINSTR) break;           // uniform
             const bool ok = (unsigned)(sy0 + (pyx[i] & 0xffff)) < (unsigned)p.H &&
                             (unsigned)(sx0 + (pyx[i] >> 16)) < (unsigned)p.W;
             const char* src = ok ? origin + prel[i] : zero;
@@ -157,7 +196,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_c64_kernel(const PatchConvPara
     };
     issue_patch(blockIdx.x + g * gridDim.x);              // tile k = g (or none)
 
-    // Fragment addresses, all of the per-lane part worked out once: a K step then issues its 8
+    // Fragment addresses, all of the per-lane part worked out once: a K step then issues its
     // LDS reads with immediate offsets and no vector arithmetic (one wave per SIMD multiplies,
     // and a wave issues at most one instruction every four cycles, so every address
     // instruction in the loop displaces an MFMA).  The patch's slot swizzle goes by the pixel's
@@ -173,7 +212,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_c64_kernel(const PatchConvPara
         abase_hi[kk] = abase[kk] + 65536;           // the last tap lies past the 16-bit offset field
 #pragma unroll
         for (int dx = 0; dx < 3; ++dx)
-            bbase[dx][kk] = lds_x + (((cw * 4 * PC_P + lr + dx) * 128 +
+            bbase[dx][kk] = lds_x + (((cw * MT * PC_P + lr + dx) * 128 +
                                       ((kc ^ ((lr + dx) & 7)) << 4)) ^ (kk << 6));
     }
 
@@ -181,24 +220,45 @@ __global__ __launch_bounds__(512, 1) void conv3x3_c64_kernel(const PatchConvPara
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 
-    f32x4 acc[4][4];
+    f32x4 acc[4][MT];
+    // residual of the tile being multiplied (PW): requested when its multiply starts, consumed
+    // a phase later by the same waves, so the loads of BOTH groups are in flight at any time
+    constexpr int NQ = PC_N3 / 32;                        // chunks of 32 output channels
+    pc_u32x4 R[PW ? NQ : 1][MT];
+    const int chb = ((kc & 1) * 32) + ((kc >> 1) * 16);   // lane's 16 bytes inside 64 of a pixel
     for (int f = 0; f <= n; ++f) {
         if (((f ^ g) & 1) == 0) {
             // ---- multiply tile f (if there is one)
             if (f < n) {
+                if constexpr (PW != 0) {
+                    // A pixel outside the image reads the residual of the nearest one inside
+                    // (an unconditional load keeps the queue countable).
+                    const PcTile tm = pc_tile<G::TY>(p, blockIdx.x + f * gridDim.x);
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) {
+                        const int oy = tm.y0 + cw * MT + mt, ox = tm.x0 + lr;
+                        const int cy = oy < p.H ? oy : p.H - 1, cx = ox < p.W ? ox : p.W - 1;
+                        const char* rp = reinterpret_cast<const char*>(p.res) +
+                                         (((long)tm.b * p.H + cy) * p.W + cx) * (PC_N3 * 2) + chb;
+#pragma unroll
+                        for (int q = 0; q < NQ; ++q)
+                            R[q][mt] = __builtin_nontemporal_load(
+                                reinterpret_cast<const pc_u32x4*>(rp + q * 64));
+                    }
+                }
 #pragma unroll
                 for (int a = 0; a < 4; ++a)
 #pragma unroll
-                    for (int mt = 0; mt < 4; ++mt) acc[a][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-                // The 8 fragment reads of K step s + 1 are issued before step s is multiplied
-                // and step s waits with a COUNTED lgkmcnt(8): LDS reads return in order, so
-                // "all but the 8 youngest" is exactly step s.  The reads and the waits are
+                    for (int mt = 0; mt < MT; ++mt) acc[a][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                // The fragment reads of K step s + 1 are issued before step s is multiplied
+                // and step s waits with a COUNTED lgkmcnt: LDS reads return in order, so "all
+                // but the youngest 4 + MT" is exactly step s.  The reads and the waits are
                 // inline assembly because the compiler, left to schedule them, sinks every read
                 // down to its first use and waits for an empty queue (one exposed LDS round
                 // trip per 8 MFMAs: measured 55 % of the register-only MFMA rate).  A wait
                 // names the registers it guards as operands, so no MFMA can move above it.
-                pc_u32x4 fa[2][4], fb[2][4];
-                auto load_step = [&](int s, pc_u32x4(&qa)[4], pc_u32x4(&qb)[4]) {
+                pc_u32x4 fa[2][4], fb[2][MT];
+                auto load_step = [&](int s, pc_u32x4(&qa)[4], pc_u32x4(&qb)[MT]) {
                     const int tap = s >> 1, kk = s & 1;
 #pragma unroll
                     for (int a = 0; a < 4; ++a) {
@@ -211,7 +271,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_c64_kernel(const PatchConvPara
                                          : "=v"(qa[a]) : "v"(abase_hi[kk]), "n"(off >= 65536 ? off - 65536 : 0));
                     }
 #pragma unroll
-                    for (int mt = 0; mt < 4; ++mt)
+                    for (int mt = 0; mt < MT; ++mt)
                         asm volatile("ds_read_b128 %0, %1 offset:%2"
                                      : "=v"(qb[mt])
                                      : "v"(bbase[tap % 3][kk]), "n"((mt + tap / 3) * (PC_P * 128)));
@@ -220,21 +280,31 @@ __global__ __launch_bounds__(512, 1) void conv3x3_c64_kernel(const PatchConvPara
 #pragma unroll
                 for (int s = 0; s < 18; ++s) {
                     pc_u32x4(&qa)[4] = fa[s & 1];
-                    pc_u32x4(&qb)[4] = fb[s & 1];
-                    if (s + 1 < 18) {
-                        load_step(s + 1, fa[(s + 1) & 1], fb[(s + 1) & 1]);
-                        asm volatile("s_waitcnt lgkmcnt(8)"
-                                     : "+v"(qa[0]), "+v"(qa[1]), "+v"(qa[2]), "+v"(qa[3]),
-                                       "+v"(qb[0]), "+v"(qb[1]), "+v"(qb[2]), "+v"(qb[3]));
+                    pc_u32x4(&qb)[MT] = fb[s & 1];
+                    if (s + 1 < 18) load_step(s + 1, fa[(s + 1) & 1], fb[(s + 1) & 1]);
+                    if constexpr (MT == 4) {
+                        if (s + 1 < 18)
+                            asm volatile("s_waitcnt lgkmcnt(8)"
+                                         : "+v"(qa[0]), "+v"(qa[1]), "+v"(qa[2]), "+v"(qa[3]),
+                                           "+v"(qb[0]), "+v"(qb[1]), "+v"(qb[2]), "+v"(qb[3]));
+                        else
+                            asm volatile("s_waitcnt lgkmcnt(0)"
+                                         : "+v"(qa[0]), "+v"(qa[1]), "+v"(qa[2]), "+v"(qa[3]),
+                                           "+v"(qb[0]), "+v"(qb[1]), "+v"(qb[2]), "+v"(qb[3]));
                     } else {
-                        asm volatile("s_waitcnt lgkmcnt(0)"
-                                     : "+v"(qa[0]), "+v"(qa[1]), "+v"(qa[2]), "+v"(qa[3]),
-                                       "+v"(qb[0]), "+v"(qb[1]), "+v"(qb[2]), "+v"(qb[3]));
+                        if (s + 1 < 18)
+                            asm volatile("s_waitcnt lgkmcnt(6)"
+                                         : "+v"(qa[0]), "+v"(qa[1]), "+v"(qa[2]), "+v"(qa[3]),
+                                           "+v"(qb[0]), "+v"(qb[1]));
+                        else
+                            asm volatile("s_waitcnt lgkmcnt(0)"
+                                         : "+v"(qa[0]), "+v"(qa[1]), "+v"(qa[2]), "+v"(qa[3]),
+                                           "+v"(qb[0]), "+v"(qb[1]));
                     }
 #pragma unroll
                     for (int a = 0; a < 4; ++a)
 #pragma unroll
-                        for (int mt = 0; mt < 4; ++mt)
+                        for (int mt = 0; mt < MT; ++mt)
                             acc[a][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
                                 __builtin_bit_cast(pc_bf16x8, qa[a]),
                                 __builtin_bit_cast(pc_bf16x8, qb[mt]), acc[a][mt], 0, 0, 0);
@@ -245,40 +315,160 @@ __global__ __launch_bounds__(512, 1) void conv3x3_c64_kernel(const PatchConvPara
         } else if (f >= 1) {
             // ---- finish tile f - 1: next patch first (the loads fly under the conversion)
             issue_patch(blockIdx.x + (f + 1) * gridDim.x);
-            const PcTile tl = pc_tile(p, blockIdx.x + (f - 1) * gridDim.x);
-            // lane's 16 bytes of a pixel: rows 0 / 2 belong to the even channel tile of a pair
-            const int chb = ((kc & 1) * 32) + ((kc >> 1) * 16);
+            const PcTile tl = pc_tile<G::TY>(p, blockIdx.x + (f - 1) * gridDim.x);
+            const bool full = tl.y0 + G::TY <= p.H && tl.x0 + PC_TX <= p.W;
+            if constexpr (PW != 0) {
+                // ---- the 64-channel tile, rounded to bf16 as the 3x3 layer's output would be,
+                // is the activation operand of the pointwise layer; it never leaves registers.
+                // (The scale / shift tables and the pointwise weights lie past the 16-bit
+                // offset field of an LDS read: one opaque per-lane OFFSET each, or every row's
+                // address is kept in a register.  An offset, not a pointer: the pointer must
+                // stay visibly an LDS one, or the reads become flat loads that cannot be
+                // waited for by count.)
+                int k4 = kc * 4, a3o0 = aoff, a3o1 = aoff ^ 64;
+                asm volatile("" : "+v"(k4), "+v"(a3o0), "+v"(a3o1));
+                const float* s2p = ssl + k4;
+                const float* s3p = ssl3 + k4;
+                const char* a3p[2] = {w3l + a3o0, w3l + a3o1};   // the two 32-channel halves
+                uint32_t P[4][MT][2];
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {                 // channel-tile pairs (0, 1), (2, 3)
-                const int n0 = (2 * j) * 16 + kc * 4, n1 = n0 + 16;
-                const f32x4 sc0 = *reinterpret_cast<const f32x4*>(ssl + n0);
-                const f32x4 sh0 = *reinterpret_cast<const f32x4*>(ssl + 64 + n0);
-                const f32x4 sc1 = *reinterpret_cast<const f32x4*>(ssl + n1);
-                const f32x4 sh1 = *reinterpret_cast<const f32x4*>(ssl + 64 + n1);
+                for (int a = 0; a < 4; ++a) {
+                    const f32x4 sc = *reinterpret_cast<const f32x4*>(s2p + a * 16);
+                    const f32x4 sh = *reinterpret_cast<const f32x4*>(s2p + 64 + a * 16);
 #pragma unroll
-                for (int mt = 0; mt < 4; ++mt) {
-                    const f32x4 c0 = acc[2 * j][mt], c1 = acc[2 * j + 1][mt];
-                    const uint32_t x0 = pc_act_pack(c0.x, c0.y, sc0.x, sc0.y, sh0.x, sh0.y, AFFINE, RELU);
-                    const uint32_t x1 = pc_act_pack(c0.z, c0.w, sc0.z, sc0.w, sh0.z, sh0.w, AFFINE, RELU);
-                    const uint32_t y0 = pc_act_pack(c1.x, c1.y, sc1.x, sc1.y, sh1.x, sh1.y, AFFINE, RELU);
-                    const uint32_t y1 = pc_act_pack(c1.z, c1.w, sc1.z, sc1.w, sh1.z, sh1.w, AFFINE, RELU);
-                    // odd rows of x <-> even rows of y
-                    const pc_u32x2 s0 = __builtin_amdgcn_permlane16_swap(x0, y0, false, false);
-                    const pc_u32x2 s1 = __builtin_amdgcn_permlane16_swap(x1, y1, false, false);
-                    const uint4 o = make_uint4(s0.x, s1.x, s0.y, s1.y);
-                    const int oy = tl.y0 + cw * 4 + mt, ox = tl.x0 + lr;
-                    if (oy < p.H && ox < p.W)
-                        *reinterpret_cast<uint4*>(reinterpret_cast<char*>(p.y) +
-                                                  ((((long)tl.b * p.H + oy) * p.W + ox) * 128 +
-                                                   j * 64 + chb)) = o;
+                    for (int mt = 0; mt < MT; ++mt) {
+                        const f32x4 c = acc[a][mt];
+                        P[a][mt][0] = pc_act_pack(c.x, c.y, sc.x, sc.y, sh.x, sh.y, AFFINE, RELU);
+                        P[a][mt][1] = pc_act_pack(c.z, c.w, sc.z, sc.w, sh.z, sh.w, AFFINE, RELU);
+                    }
                 }
+                // B fragment of (pixel row mt, 32-channel half kk): lane (lr, kc) needs channels
+                // 32 kk + 8 kc .. + 7 of pixel lr, which sit in lanes (lr, 2 (kc & 1)) and the row
+                // after it, in channel tile 2 kk + (kc >> 1).  Two row swaps bring them home: the
+                // upper 32 lanes of tile 2 kk against the lower 32 of tile 2 kk + 1, then odd
+                // against even rows.
+                pc_u32x4 Bc[MT][2];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                        for (int e = 0; e < 2; ++e) {
+                            const pc_u32x2 t = __builtin_amdgcn_permlane32_swap(
+                                P[2 * kk][mt][e], P[2 * kk + 1][mt][e], false, false);
+                            const pc_u32x2 u = __builtin_amdgcn_permlane16_swap(t.x, t.y, false, false);
+                            Bc[mt][kk][e] = u.x;
+                            Bc[mt][kk][2 + e] = u.y;
+                        }
+                // One pointer per pixel row into the output; a chunk of 32 channels is an immediate
+                // offset from it (q * 64 bytes).  A pixel outside the image stores to a sink: an
+                // unconditional store keeps the queue countable.
+                char* yp[MT];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const int oy = tl.y0 + cw * MT + mt, ox = tl.x0 + lr;
+                    const bool ok = oy < p.H && ox < p.W;
+                    yp[mt] = ok ? reinterpret_cast<char*>(p.y) +
+                                      ((((long)tl.b * p.H + oy) * p.W + ox) * (PC_N3 * 2) + chb)
+                                : reinterpret_cast<char*>(g_pc_sink) + lane * 16;
+                }
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    // the chunk's weights: rows 32 q .. + 31 of the pointwise filter, from LDS
+                    pc_u32x4 A3[2][2];
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                        for (int kk = 0; kk < 2; ++kk)
+                            A3[nt][kk] = *reinterpret_cast<const pc_u32x4*>(
+                                a3p[kk] + (q * 32 + nt * 16) * 128);
+                    f32x4 c3[2][MT];
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt) c3[nt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                            for (int mt = 0; mt < MT; ++mt)
+                                c3[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                                    __builtin_bit_cast(pc_bf16x8, A3[nt][kk]),
+                                    __builtin_bit_cast(pc_bf16x8, Bc[mt][kk]), c3[nt][mt], 0, 0, 0);
+                    const f32x4 s0 = *reinterpret_cast<const f32x4*>(s3p + q * 32);
+                    const f32x4 h0 = *reinterpret_cast<const f32x4*>(s3p + PC_N3 + q * 32);
+                    const f32x4 s1 = *reinterpret_cast<const f32x4*>(s3p + q * 32 + 16);
+                    const f32x4 h1 = *reinterpret_cast<const f32x4*>(s3p + PC_N3 + q * 32 + 16);
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) {
+                        // The residual arrives as 8 contiguous channels per lane; the same row
+                        // swap that builds that layout for the store takes it apart again.
+                        // (Pinned here by a volatile statement: the optimiser would otherwise run
+                        // the swaps right behind the load, chunks early, and wait for it there.)
+                        pc_u32x4 r = R[q][mt];
+                        asm volatile("" : "+v"(r));
+                        const pc_u32x2 ra = __builtin_amdgcn_permlane16_swap(r.x, r.z, false, false);
+                        const pc_u32x2 rb = __builtin_amdgcn_permlane16_swap(r.y, r.w, false, false);
+                        const f32x4 a = c3[0][mt], b = c3[1][mt];
+                        float v[8] = {fmaf(a.x, s0.x, h0.x), fmaf(a.y, s0.y, h0.y), fmaf(a.z, s0.z, h0.z),
+                                      fmaf(a.w, s0.w, h0.w), fmaf(b.x, s1.x, h1.x), fmaf(b.y, s1.y, h1.y),
+                                      fmaf(b.z, s1.z, h1.z), fmaf(b.w, s1.w, h1.w)};
+                        const uint32_t ru[4] = {ra.x, rb.x, ra.y, rb.y};   // tile 2q: 2 words, tile 2q+1: 2
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            v[2 * i] += bf16_bits_to_float(ru[i] & 0xffffu);
+                            v[2 * i + 1] += bf16_bits_to_float(ru[i] >> 16);
+                        }
+                        if (PW == 1) {
+#pragma unroll
+                            for (int i = 0; i < 8; ++i) v[i] = fmaxf(v[i], 0.0f);
+                        }
+                        const uint32_t x0 = pack_bf16x2_bits(v[0], v[1]), x1 = pack_bf16x2_bits(v[2], v[3]);
+                        const uint32_t y0 = pack_bf16x2_bits(v[4], v[5]), y1 = pack_bf16x2_bits(v[6], v[7]);
+                        const pc_u32x2 o0 = __builtin_amdgcn_permlane16_swap(x0, y0, false, false);
+                        const pc_u32x2 o1 = __builtin_amdgcn_permlane16_swap(x1, y1, false, false);
+                        const pc_u32x4 o = {o0.x, o1.x, o0.y, o1.y};
+                        *reinterpret_cast<pc_u32x4*>(yp[mt] + q * 64) = o;
+                    }
+                }
+                // The patch requests are older than this tile's NQ * MT stores, every one of
+                // which was issued (to the image or to the sink), and vector memory operations
+                // retire in order: "all but NQ * MT" means the patch has landed.
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NQ * MT) : "memory");
+            } else {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {             // channel-tile pairs (0, 1), (2, 3)
+                    const int n0 = (2 * j) * 16 + kc * 4, n1 = n0 + 16;
+                    const f32x4 sc0 = *reinterpret_cast<const f32x4*>(ssl + n0);
+                    const f32x4 sh0 = *reinterpret_cast<const f32x4*>(ssl + 64 + n0);
+                    const f32x4 sc1 = *reinterpret_cast<const f32x4*>(ssl + n1);
+                    const f32x4 sh1 = *reinterpret_cast<const f32x4*>(ssl + 64 + n1);
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) {
+                        const f32x4 c0 = acc[2 * j][mt], c1 = acc[2 * j + 1][mt];
+                        const uint32_t x0 = pc_act_pack(c0.x, c0.y, sc0.x, sc0.y, sh0.x, sh0.y, AFFINE, RELU);
+                        const uint32_t x1 = pc_act_pack(c0.z, c0.w, sc0.z, sc0.w, sh0.z, sh0.w, AFFINE, RELU);
+                        const uint32_t y0 = pc_act_pack(c1.x, c1.y, sc1.x, sc1.y, sh1.x, sh1.y, AFFINE, RELU);
+                        const uint32_t y1 = pc_act_pack(c1.z, c1.w, sc1.z, sc1.w, sh1.z, sh1.w, AFFINE, RELU);
+                        // odd rows of x <-> even rows of y
+                        const pc_u32x2 s0 = __builtin_amdgcn_permlane16_swap(x0, y0, false, false);
+                        const pc_u32x2 s1 = __builtin_amdgcn_permlane16_swap(x1, y1, false, false);
+                        const uint4 o = make_uint4(s0.x, s1.x, s0.y, s1.y);
+                        const int oy = tl.y0 + cw * MT + mt, ox = tl.x0 + lr;
+                        if (oy < p.H && ox < p.W)
+                            *reinterpret_cast<uint4*>(reinterpret_cast<char*>(p.y) +
+                                                      ((((long)tl.b * p.H + oy) * p.W + ox) * 128 +
+                                                       j * 64 + chb)) = o;
+                    }
+                }
+                // The patch requests are older than the 2 MT stores, and vector memory
+                // operations retire in order: a tile that lies wholly inside the image issued
+                // all of them, so "all but 2 MT" means the patch has landed; an edge tile may
+                // have skipped some.
+                if (full) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * MT) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
-            // The patch requests are older than the 8 stores, and vector memory operations
-            // retire in order: a tile that lies wholly inside the image issued all 8 stores,
-            // so "all but 8" means the patch has landed; an edge tile may have skipped some.
-            const bool full = tl.y0 + PC_T <= p.H && tl.x0 + PC_T <= p.W;
-            if (full) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
@@ -289,16 +479,26 @@ __global__ __launch_bounds__(512, 1) void conv3x3_c64_kernel(const PatchConvPara
 
 using namespace pe;
 
-extern "C" int32_t pe_conv3x3_c64_fwd_bf16(int32_t B, int32_t H, int32_t W, const void* x,
-                                           const void* w, const float* scale, const float* shift,
-                                           int32_t relu, void* y, pe_stream_t stream) {
-    const char* what = "pe_conv3x3_c64_fwd_bf16";
+template <int R, bool A, int P>
+static hipError_t pc_launch_variant(const PatchConvParams& p, unsigned nwg, hipStream_t stream) {
+    const hipError_t e = pe::ensure_dynamic_lds<&conv3x3_c64_kernel<R, A, P>>(PcGeo<P>::LDS);
+    if (e == hipSuccess)
+        pe::launch(conv3x3_c64_kernel<R, A, P>, nwg, 512, (size_t)PcGeo<P>::LDS, stream, p);
+    return e;
+}
+
+// Shared launch: pw 0 = the 3x3 layer alone, 1 / 2 = with the pointwise layer (ReLU / none).
+static int32_t pc_launch(const char* what, int32_t B, int32_t H, int32_t W, const void* x,
+                         const void* w, const float* scale, const float* shift, int32_t relu,
+                         const void* w3, const float* scale3, const float* shift3,
+                         const void* residual, int pw, void* y, pe_stream_t stream) {
     PE_REQUIRE(x && w && y, PE_E_INVALID, "%s: NULL pointer", what);
     PE_REQUIRE(B > 0 && H > 0 && W > 0, PE_E_INVALID, "%s: sizes must be positive", what);
     PE_REQUIRE(H <= 8192 && W <= 8192, PE_E_UNSUPPORTED, "%s: images above 8192 x 8192", what);
     PE_REQUIRE(relu >= 0 && relu <= 2, PE_E_INVALID, "%s: relu must be 0, 1 or 2", what);
     PE_REQUIRE(aligned(x, 16) && aligned(w, 16) && aligned(y, 16) && aligned(scale, 16) &&
-                   aligned(shift, 16),
+                   aligned(shift, 16) && aligned(w3, 16) && aligned(scale3, 16) &&
+                   aligned(shift3, 16) && aligned(residual, 16),
                PE_E_INVALID, "%s: tensors must be 16-byte aligned", what);
     PatchConvParams p;
     p.x = static_cast<const uint16_t*>(x);
@@ -306,31 +506,60 @@ extern "C" int32_t pe_conv3x3_c64_fwd_bf16(int32_t B, int32_t H, int32_t W, cons
     p.scale = scale;
     p.shift = shift;
     p.y = static_cast<uint16_t*>(y);
+    p.w3 = static_cast<const uint16_t*>(w3);
+    p.scale3 = scale3;
+    p.shift3 = shift3;
+    p.res = static_cast<const uint16_t*>(residual);
     p.B = B;
     p.H = H;
     p.W = W;
-    p.relu = relu;
-    p.tiles_x = (W + PC_T - 1) / PC_T;
-    p.tiles_y = (H + PC_T - 1) / PC_T;
+    const int ty = pw ? PcGeo<1>::TY : PcGeo<0>::TY;
+    p.tiles_x = (W + PC_TX - 1) / PC_TX;
+    p.tiles_y = (H + ty - 1) / ty;
     const long ntiles = (long)B * p.tiles_x * p.tiles_y;
     PE_REQUIRE(ntiles < 0x3fffffffL, PE_E_UNSUPPORTED, "%s: too many tiles", what);
     p.ntiles = (int)ntiles;
     int dev = 0, cus = 256;
     if (hipGetDevice(&dev) == hipSuccess)
         (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    const long nwg = ntiles < cus ? ntiles : cus;   // one persistent workgroup per CU (154 KB of LDS)
+    const unsigned nwg = (unsigned)(ntiles < cus ? ntiles : cus);   // one persistent workgroup per CU
     const bool affine = scale != nullptr || shift != nullptr;
+    hipStream_t st = as_stream(stream);
     hipError_t e = hipSuccess;
-#define PC_CASE(R, A)                                                                           \
-    if (relu == R && affine == A) {                                                             \
-        e = pe::ensure_dynamic_lds<&conv3x3_c64_kernel<R, A>>(PC_LDS);                       \
-        if (e == hipSuccess)                                                                    \
-            pe::launch(conv3x3_c64_kernel<R, A>, (unsigned)nwg, 512, (size_t)PC_LDS,         \
-                       as_stream(stream), p);                                                   \
-    }
-    PC_CASE(0, false) PC_CASE(1, false) PC_CASE(2, false)
-    PC_CASE(0, true) PC_CASE(1, true) PC_CASE(2, true)
-#undef PC_CASE
+    bool launched = true;
+    if (pw == 0 && !affine && relu == 0) e = pc_launch_variant<0, false, 0>(p, nwg, st);
+    else if (pw == 0 && !affine && relu == 1) e = pc_launch_variant<1, false, 0>(p, nwg, st);
+    else if (pw == 0 && !affine && relu == 2) e = pc_launch_variant<2, false, 0>(p, nwg, st);
+    else if (pw == 0 && affine && relu == 0) e = pc_launch_variant<0, true, 0>(p, nwg, st);
+    else if (pw == 0 && affine && relu == 1) e = pc_launch_variant<1, true, 0>(p, nwg, st);
+    else if (pw == 0 && affine && relu == 2) e = pc_launch_variant<2, true, 0>(p, nwg, st);
+    else if (pw == 1 && affine && relu == 1) e = pc_launch_variant<1, true, 1>(p, nwg, st);
+    else if (pw == 2 && affine && relu == 1) e = pc_launch_variant<1, true, 2>(p, nwg, st);
+    else launched = false;
+    PE_REQUIRE(launched, PE_E_UNSUPPORTED,
+               "%s: the fused pointwise layer needs scale / shift and ReLU on the 3x3 layer", what);
     PE_REQUIRE(e == hipSuccess, PE_E_HIP, "%s: LDS opt-in: %s", what, hipGetErrorString(e));
     return check_launch(what);
+}
+
+extern "C" int32_t pe_conv3x3_c64_fwd_bf16(int32_t B, int32_t H, int32_t W, const void* x,
+                                           const void* w, const float* scale, const float* shift,
+                                           int32_t relu, void* y, pe_stream_t stream) {
+    return pc_launch("pe_conv3x3_c64_fwd_bf16", B, H, W, x, w, scale, shift, relu, nullptr, nullptr,
+                     nullptr, nullptr, 0, y, stream);
+}
+
+extern "C" int32_t pe_conv3x3_c64_pw_fwd_bf16(int32_t B, int32_t H, int32_t W, const void* x,
+                                              const void* w, const float* scale, const float* shift,
+                                              int32_t relu, const void* w3, int32_t Cout3,
+                                              const float* scale3, const float* shift3,
+                                              const void* residual, int32_t relu3, void* y,
+                                              pe_stream_t stream) {
+    const char* what = "pe_conv3x3_c64_pw_fwd_bf16";
+    PE_REQUIRE(w3 && residual, PE_E_INVALID, "%s: NULL pointer", what);
+    PE_REQUIRE(Cout3 == PC_N3, PE_E_UNSUPPORTED, "%s: the pointwise layer must have %d outputs", what,
+               PC_N3);
+    PE_REQUIRE(relu3 == 0 || relu3 == 1, PE_E_INVALID, "%s: relu3 must be 0 or 1", what);
+    return pc_launch(what, B, H, W, x, w, scale, shift, relu, w3, scale3, shift3, residual,
+                     relu3 ? 1 : 2, y, stream);
 }

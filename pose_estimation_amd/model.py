@@ -293,6 +293,20 @@ class PoseResNet:
     def _chainable(self, b: BlockSpec) -> bool:
         return self.chain and b.c2.cout == 64 and b.c2.cin == 64 and b.c2.stride == 1
 
+    # conv2 (3x3 64 -> 64) and conv3 (1x1 64 -> 256, residual, ReLU) of a first-stage bottleneck
+    # as ONE launch (pe_conv3x3_c64_pw_fwd_bf16): the 64-channel tensor between them (100 MB at
+    # batch 256) is never written or read back.  Bit-identical to the two launches; taken when
+    # the layer has at least `pnn.PATCH3X3_MIN_TILES` 16 x 16 tiles (one persistent workgroup
+    # per CU).  PE_RESNET_FUSE_C2C3=0: two launches (comparison).
+    fuse_c2c3 = os.environ.get("PE_RESNET_FUSE_C2C3", "1") != "0"
+
+    def _c2c3_fusable(self, b: BlockSpec, x: torch.Tensor) -> bool:
+        c2, c3 = b.c2, b.c3
+        B, H, W, _ = x.shape
+        return (self.fuse_c2c3 and c2.cin == 64 and c2.cout == 64 and c2.k == 3 and c2.stride == 1
+                and c2.pad == 1 and c2.relu and c3.k == 1 and c3.cout == 256 and c3.stride == 1
+                and B * ((H + 15) // 16) * ((W + 15) // 16) >= pnn.PATCH3X3_MIN_TILES)
+
     def _blocks(self, x: torch.Tensor, blocks, out: Optional[torch.Tensor]) -> torch.Tensor:
         side = self._side_stream() if self.down_stream else None
         c1_out = None   # conv1 of the current block, when the previous block's chain made it
@@ -322,6 +336,21 @@ class PoseResNet:
                 continue
             have_c1, c1_out = c1_out, None
             kw = {"out": out} if (out is not None and bi == len(blocks) - 1) else {}
+            if self._c2c3_fusable(b, x):
+                main = torch.cuda.current_stream(self.device)
+                if b.down and side is not None:
+                    side.wait_stream(main)
+                    with torch.cuda.stream(side):
+                        idn = self._conv(b.down, x)
+                    o1 = have_c1 if have_c1 is not None else self._conv(b.c1, x)
+                    main.wait_stream(side)
+                else:
+                    o1 = have_c1 if have_c1 is not None else self._conv(b.c1, x)
+                    idn = self._conv(b.down, x) if b.down else x
+                x = pnn.conv3x3_c64_pw(o1, self.w(b.c2), self.scale[b.c2.name], self.shift[b.c2.name],
+                                       self.w(b.c3), self.scale[b.c3.name], self.shift[b.c3.name],
+                                       idn, True, **kw)
+                continue
             if b.down and side is not None:
                 # the projection of the skip path runs beside conv1 / conv2 (it is bound by
                 # memory traffic, conv2 by the matrix cores); both streams wait for each other,

@@ -287,6 +287,34 @@ def conv3x3_c64(x: torch.Tensor, w: torch.Tensor, scale=None, shift=None, relu: 
     return out
 
 
+def conv3x3_c64_pw(x: torch.Tensor, w: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor,
+                   w3: torch.Tensor, scale3, shift3, residual: torch.Tensor, relu3: bool = True,
+                   out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """conv3x3_c64(x, w, scale, shift, relu=1) followed by the pointwise layer w3 [256,1,1,64]
+    (+ scale3, shift3, residual, ReLU) in one launch (pe_conv3x3_c64_pw_fwd_bf16): the
+    64-channel tensor between them is never written.  Equals
+    conv2d(conv2d(x, w, scale, shift, None, 1, 1, True), w3, scale3, shift3, residual, relu=relu3)
+    bit for bit."""
+    _check_act(x)
+    _need_gpu(w, scale, shift, w3, scale3, shift3, residual, out)
+    B, H, W, C = x.shape
+    if C != 64 or tuple(w.shape) != (64, 3, 3, 64) or w.dtype != BF16 or not w.is_contiguous():
+        raise ValueError("conv3x3_c64_pw expects x [...,64] and w contiguous bfloat16 [64,3,3,64]")
+    N3 = w3.shape[0]
+    if w3.numel() != N3 * 64 or w3.dtype != BF16 or not w3.is_contiguous():
+        raise ValueError("w3 must be contiguous bfloat16 [Cout3,1,1,64]")
+    if tuple(residual.shape) != (B, H, W, N3) or residual.dtype != BF16 or not residual.is_contiguous():
+        raise ValueError("residual must be contiguous bfloat16 [B,H,W,Cout3]")
+    if out is None:
+        out = torch.empty((B, H, W, N3), dtype=BF16, device=x.device)
+    with on_device(x):
+        check(lib().pe_conv3x3_c64_pw_fwd_bf16(B, H, W, x.data_ptr(), w.data_ptr(), _ptr(scale),
+                                               _ptr(shift), 1, w3.data_ptr(), N3, _ptr(scale3),
+                                               _ptr(shift3), residual.data_ptr(), int(relu3),
+                                               out.data_ptr(), _stream(x)))
+    return out
+
+
 def stem7x7s2_pool(x_s2d: torch.Tensor, w: torch.Tensor, scale=None, shift=None,
                    out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """stem7x7s2 (+ scale, shift, ReLU) followed by maxpool3x3s2 in one launch:

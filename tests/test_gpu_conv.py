@@ -225,6 +225,54 @@ def test_conv3x3_64_channels_resident_filter_kernel(case):
         assert torch.equal(goti.float().cpu(), ref)
 
 
+@pytest.mark.parametrize("case", [(2, 64, 48), (5, 16, 16), (1, 7, 5), (3, 33, 50), (300, 16, 12)])
+def test_conv3x3_64_channels_with_the_pointwise_layer_in_the_same_launch(case):
+    """pe_conv3x3_c64_pw_fwd_bf16 (conv2 + conv3 of a first-stage bottleneck, residual and ReLU)
+    against the two engine launches it replaces, bit for bit, with and without the last ReLU;
+    exact against the oracle on integer operands."""
+    B, H, W = case
+    g = torch.Generator().manual_seed(9 + H + W)
+    x = rand_bf16((B, H, W, 64), g).to(BF16).cuda()
+    w = pnn.pack_conv_weight(rand_bf16((64, 64, 3, 3), g, (2.0 / 576) ** 0.5)).cuda()
+    w3 = pnn.pack_conv_weight(rand_bf16((256, 64, 1, 1), g, (2.0 / 64) ** 0.5)).cuda()
+    scale = (torch.rand(64, generator=g) + 0.5).cuda()
+    shift = (torch.randn(64, generator=g) * 0.1).cuda()
+    scale3 = (torch.rand(256, generator=g) + 0.5).cuda()
+    shift3 = (torch.randn(256, generator=g) * 0.1).cuda()
+    res = rand_bf16((B, H, W, 256), g).to(BF16).cuda()
+    for sc3, sh3, relu3 in ((scale3, shift3, True), (None, None, False), (None, shift3, True)):
+        mid = pnn.conv2d(x, w, scale, shift, None, 1, 1, True)
+        want = pnn.conv2d(mid, w3, sc3, sh3, res, 1, 0, relu3)
+        got = pnn.conv3x3_c64_pw(x, w, scale, shift, w3, sc3, sh3, res, relu3)
+        assert torch.equal(got, want), (sc3 is not None, relu3)
+    if B <= 5:
+        xi = int_tensor((B, H, W, 64), g, -2, 2)
+        wi = int_tensor((64, 64, 3, 3), g, -1, 1)
+        w3i = int_tensor((256, 64, 1, 1), g, -1, 1)
+        ri = int_tensor((B, H, W, 256), g, -3, 3)
+        one = torch.ones(64).cuda()
+        zero = torch.zeros(64).cuda()
+        mid = torch.relu(to.bf16r(to.conv2d(xi, wi, stride=1, pad=1)))
+        ref = to.bf16r(torch.relu(to.conv2d(mid, w3i, stride=1, pad=0) + ri))
+        goti = pnn.conv3x3_c64_pw(xi.to(BF16).cuda(), pnn.pack_conv_weight(wi).cuda(), one, zero,
+                                  pnn.pack_conv_weight(w3i).cuda(), None, None, ri.to(BF16).cuda())
+        assert torch.equal(goti.float().cpu(), ref)
+
+
+def test_conv3x3_pointwise_rejects_what_it_does_not_cover():
+    x = torch.zeros((1, 16, 16, 64), dtype=BF16).cuda()
+    w = torch.zeros((64, 3, 3, 64), dtype=BF16).cuda()
+    s = torch.ones(64).cuda()
+    w3 = torch.zeros((128, 1, 1, 64), dtype=BF16).cuda()
+    res = torch.zeros((1, 16, 16, 128), dtype=BF16).cuda()
+    with pytest.raises(RuntimeError, match="256 outputs"):
+        pnn.conv3x3_c64_pw(x, w, s, s, w3, None, None, res)
+    w3 = torch.zeros((256, 1, 1, 64), dtype=BF16).cuda()
+    res = torch.zeros((1, 16, 16, 256), dtype=BF16).cuda()
+    with pytest.raises(RuntimeError, match="scale / shift"):
+        pnn.conv3x3_c64_pw(x, w, None, None, w3, None, None, res)
+
+
 @pytest.mark.parametrize("case", [(2, 64, 48), (3, 128, 96), (1, 16, 12), (2, 40, 72), (1, 8, 4),
                                   (5, 36, 68)])
 def test_stem_and_pool_in_one_launch(case):
