@@ -375,7 +375,17 @@ class PoseHRNet:
         x = self._unit(sp.stem[1], x)
         for b in sp.layer1:
             idn = self._unit(b.down, x) if b.down else x
-            x = self._unit(b.c3, self._unit(b.c2, self._unit(b.c1, x)), residual=idn, relu=True)
+            c2, c3 = b.c2.name, b.c3.name
+            B, H, W, _ = x.shape
+            if (b.c2.k == 3 and b.c2.stride == 1 and b.c3.k == 1 and b.c3.stride == 1
+                    and pnn.c2c3_fusable(B, H, W, p[c2 + ".weight"], p[c3 + ".weight"],
+                                         p[c2 + ".scale"], p[c2 + ".shift"])):
+                # conv2 + conv3 + residual + ReLU in one launch (bit-identical to the two)
+                x = pnn.conv3x3_c64_pw(self._unit(b.c1, x), p[c2 + ".weight"], p[c2 + ".scale"],
+                                       p[c2 + ".shift"], p[c3 + ".weight"], p[c3 + ".scale"],
+                                       p[c3 + ".shift"], idn, True)
+            else:
+                x = self._unit(b.c3, self._unit(b.c2, self._unit(b.c1, x)), residual=idn, relu=True)
         xs = [x]
         for tr, mods in zip(sp.transitions, sp.stages):
             xs = [(xs[i] if t is None else self._unit(t, xs[i])) if i < len(xs)

@@ -297,15 +297,16 @@ class PoseResNet:
     # as ONE launch (pe_conv3x3_c64_pw_fwd_bf16): the 64-channel tensor between them (100 MB at
     # batch 256) is never written or read back.  Bit-identical to the two launches; taken when
     # the layer has at least `pnn.PATCH3X3_MIN_TILES` 16 x 16 tiles (one persistent workgroup
-    # per CU).  PE_RESNET_FUSE_C2C3=0: two launches (comparison).
+    # per CU).  PE_RESNET_FUSE_C2C3=0 or PE_CONV_C2C3=0: two launches (comparison).
     fuse_c2c3 = os.environ.get("PE_RESNET_FUSE_C2C3", "1") != "0"
 
     def _c2c3_fusable(self, b: BlockSpec, x: torch.Tensor) -> bool:
-        c2, c3 = b.c2, b.c3
-        B, H, W, _ = x.shape
-        return (self.fuse_c2c3 and c2.cin == 64 and c2.cout == 64 and c2.k == 3 and c2.stride == 1
-                and c2.pad == 1 and c2.relu and c3.k == 1 and c3.cout == 256 and c3.stride == 1
-                and B * ((H + 15) // 16) * ((W + 15) // 16) >= pnn.PATCH3X3_MIN_TILES)
+        c1, c2, c3 = b.c1, b.c2, b.c3
+        B, H, W, _ = x.shape            # the block's input; conv1 keeps its size
+        return (self.fuse_c2c3 and c1.stride == 1 and c2.k == 3 and c2.stride == 1 and c2.pad == 1
+                and c2.relu and c3.k == 1 and c3.stride == 1
+                and pnn.c2c3_fusable(B, H, W, self.w(c2), self.w(c3), self.scale[c2.name],
+                                     self.shift[c2.name]))
 
     def _blocks(self, x: torch.Tensor, blocks, out: Optional[torch.Tensor]) -> torch.Tensor:
         side = self._side_stream() if self.down_stream else None

@@ -287,6 +287,19 @@ def conv3x3_c64(x: torch.Tensor, w: torch.Tensor, scale=None, shift=None, relu: 
     return out
 
 
+# conv2 (3x3 64 -> 64, folded BN, ReLU) and conv3 (1x1 64 -> 256, folded BN, residual, ReLU) of a
+# bottleneck in one launch (conv3x3_c64_pw), under the same tile-count rule as the 3x3 kernel.
+# PE_CONV_C2C3=0: always two launches (comparison).
+C2C3 = os.environ.get("PE_CONV_C2C3", "1") != "0"
+
+
+def c2c3_fusable(B: int, H: int, W: int, w2: torch.Tensor, w3: torch.Tensor, scale2, shift2) -> bool:
+    """Whether conv3x3_c64_pw covers this pair of layers on a [B,H,W,64] bf16 input."""
+    return (C2C3 and tuple(w2.shape) == (64, 3, 3, 64) and w3.shape[0] == 256
+            and w3.numel() == 256 * 64 and scale2 is not None and shift2 is not None
+            and B * ((H + 15) // 16) * ((W + 15) // 16) >= PATCH3X3_MIN_TILES)
+
+
 def conv3x3_c64_pw(x: torch.Tensor, w: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor,
                    w3: torch.Tensor, scale3, shift3, residual: torch.Tensor, relu3: bool = True,
                    out: Optional[torch.Tensor] = None) -> torch.Tensor:
