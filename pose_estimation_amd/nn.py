@@ -93,11 +93,14 @@ def _check_act(x: torch.Tensor, name: str = "x"):
 
 
 # 3x3 stride-1 pad-1 layers with 64 input and 64 output channels go through the resident-filter
-# kernel (pe_conv3x3_c64_fwd_bf16, bit-identical to the engine) once there are enough 16 x 16
-# tiles to give every CU several: one persistent workgroup per CU loads the 72 KB filter once.
-# PE_CONV_PATCH3X3=0: always the engine (comparison).
+# kernel (pe_conv3x3_c64_fwd_bf16, bit-identical to the engine) from 1024 16 x 16 tiles up.  One
+# persistent workgroup per CU loads the 72 KB filter once and holds the CU's whole LDS.  Alone it
+# beats the engine at every size tried (192 tiles: 8.1 against 12.6 us; 3072: 57 against 104 us),
+# but a launch that owns every CU cannot run beside the other branches of a multi-branch network:
+# with the threshold at 128 tiles the HRNet-style forward, whose 64-channel branch has 576, went
+# from 5.65 to 6.03 ms.  PE_CONV_PATCH3X3=0: always the engine (comparison).
 PATCH3X3 = os.environ.get("PE_CONV_PATCH3X3", "1") != "0"
-PATCH3X3_MIN_TILES = 1024
+PATCH3X3_MIN_TILES = int(os.environ.get("PE_CONV_PATCH3X3_MIN_TILES", "1024"))
 
 
 def conv2d(x: torch.Tensor, w: torch.Tensor, scale: Optional[torch.Tensor] = None,
