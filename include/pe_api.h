@@ -368,6 +368,21 @@ int32_t pe_conv3x3_c64_pw_fwd_bf16(int32_t B, int32_t H, int32_t W, const void* 
                                    const float* shift3, const void* residual, int32_t relu3,
                                    void* y, pe_stream_t stream);
 
+/* The same pair of layers for the FIRST bottleneck of a stage, whose residual is itself a
+ * pointwise projection of the block's input x0 [B,H,W,64] (the "downsample" branch):
+ * y = relu( conv1x1(bf16(act(conv3x3(x))), w3) * scale3 + shift3
+ *           + bf16( conv1x1(x0, wd) * scaled + shiftd ) ),
+ * wd [Cout3][64] bf16, scaled / shiftd [Cout3] float32 (NULL = 1 / 0).  The projection is
+ * computed per output tile inside the launch, rounded to bf16 exactly as its own launch would
+ * store it; its Cout3-channel tensor is never written or read.  Same restrictions as
+ * pe_conv3x3_c64_pw_fwd_bf16; equals the three separate launches bit for bit. */
+int32_t pe_conv3x3_c64_pw_proj_fwd_bf16(int32_t B, int32_t H, int32_t W, const void* x,
+                                        const void* w, const float* scale, const float* shift,
+                                        int32_t relu, const void* w3, int32_t Cout3,
+                                        const float* scale3, const float* shift3, const void* x0,
+                                        const void* wd, const float* scaled, const float* shiftd,
+                                        void* y, pe_stream_t stream);
+
 /* 3x3 stride-2 pad-1 stem on a 3-channel image (MobileNetV2's first conv; the reference's
  * backbone, nets/mobilenet_v2.py, PoseEstimation.pyproj:32, absent), computed over the same
  * space-to-depth image as a 2-row conv: w [Cout][2 rows][4 cols x 16] bf16 (columns 2, 3 zero),

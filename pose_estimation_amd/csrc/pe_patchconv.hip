@@ -63,7 +63,8 @@ struct PcGeo {
     static constexpr int NINSTR = (NPIX + 7) / 8;     // wave instructions of 8 pixels: 41 / 23
     static constexpr int XBYTES = NINSTR * 1024;      // per patch buffer: 41 984 / 23 552
     static constexpr int W3B = PW ? PC_W3BYTES : 0;
-    static constexpr int LDS = PC_WBYTES + W3B + 2 * XBYTES + 2 * 64 * 4 + (PW ? 2 * PC_N3 * 4 : 0);
+    static constexpr int LDS = PC_WBYTES + W3B + 2 * XBYTES + 2 * 64 * 4 + (PW ? 2 * PC_N3 * 4 : 0) +
+                               (PW == 3 ? 2 * PC_N3 * 4 : 0);
 };
 
 __device__ __attribute__((aligned(16))) uint32_t g_pc_zero16[4] = {0u, 0u, 0u, 0u};
@@ -81,6 +82,10 @@ struct PatchConvParams {
     const float* scale3;   // residual [B][H][W][256] added before its ReLU
     const float* shift3;
     const uint16_t* res;
+    const uint16_t* x0;    // projected residual (PW 3): the block's input [B][H][W][64], the
+    const uint16_t* wd;    // projection's weights [256][64] and its scale / shift [256]
+    const float* scaled;
+    const float* shiftd;
     int B, H, W;
     int tiles_x, tiles_y, ntiles;
 };
@@ -123,6 +128,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_c64_kernel(const PatchConvPara
     char* const xb0 = smem + PC_WBYTES + G::W3B;          // two patch buffers
     float* ssl = reinterpret_cast<float*>(xb0 + 2 * G::XBYTES);
     float* ssl3 = ssl + 128;
+    float* ssld = ssl3 + 2 * PC_N3;                       // PW 3 only
+    constexpr bool PROJ = PW == 3;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -160,22 +167,35 @@ __global__ __launch_bounds__(512, 1) void conv3x3_c64_kernel(const PatchConvPara
     if (PW && tid < PC_N3) {
         ssl3[tid] = p.scale3 ? p.scale3[tid] : 1.0f;
         ssl3[PC_N3 + tid] = p.shift3 ? p.shift3[tid] : 0.0f;
+        if constexpr (PROJ) {
+            ssld[tid] = p.scaled ? p.scaled[tid] : 1.0f;
+            ssld[PC_N3 + tid] = p.shiftd ? p.shiftd[tid] : 0.0f;
+        }
     }
     // tiles of this workgroup: blockIdx.x + k * gridDim.x, k = 0 .. n - 1; group g takes k = g mod 2
     const int n = (p.ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
 
     // Patch requests of this wave: blocks j = cw, cw + 4, ... of 8 pixels.  What depends on the
     // lane alone (its pixel's row and column in the patch, its byte offset from the patch
-    // origin) is worked out once; per tile a request costs two compares and a select.
+    // origin) is worked out once; per tile a request costs two compares and a select.  The
+    // variant with the projected residual is short of registers and works it out per request
+    // instead (a spilled value would be worse than both: its reload is a vector memory
+    // operation, and waiting for it drains every load and store in flight).
     constexpr int NB = (G::NINSTR + 3) / 4;               // 11 / 6
-    int prel[NB], pyx[NB];
-#pragma unroll
-    for (int i = 0; i < NB; ++i) {
-        const int pp = (i * 4 + cw) * 8 + (lane >> 3);
+    constexpr bool KEEP = PW != 3;
+    int prel[KEEP ? NB : 1], pyx[KEEP ? NB : 1];
+    auto patch_lane = [&](int i, int& rel, int& yx) {
+        int ln = lane;
+        if constexpr (!KEEP) asm volatile("" : "+v"(ln));   // per request, not hoisted
+        const int pp = (i * 4 + cw) * 8 + (ln >> 3);
         const int py = pp / PC_P, px = pp - py * PC_P;
-        const int cc = (lane & 7) ^ (px & 7);
-        prel[i] = (py * p.W + px) * 128 + cc * 16;
-        pyx[i] = pp < G::NPIX ? (py | (px << 16)) : 0x4000;   // a row no image has
+        const int cc = (ln & 7) ^ (px & 7);
+        rel = (py * p.W + px) * 128 + cc * 16;
+        yx = pp < G::NPIX ? (py | (px << 16)) : 0x4000;   // a row no image has
+    };
+    if constexpr (KEEP) {
+#pragma unroll
+        for (int i = 0; i < NB; ++i) patch_lane(i, prel[i], pyx[i]);
     }
     const char* const zero = reinterpret_cast<const char*>(g_pc_zero16);
     auto issue_patch = [&](int t) {
@@ -187,9 +207,16 @@ __global__ __launch_bounds__(512, 1) void conv3x3_c64_kernel(const PatchConvPara
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             if (i * 4 + cw >= G::NINSTR) break;           // uniform
-            const bool ok = (unsigned)(sy0 + (pyx[i] & 0xffff)) < (unsigned)p.H &&
-                            (unsigned)(sx0 + (pyx[i] >> 16)) < (unsigned)p.W;
-            const char* src = ok ? origin + prel[i] : zero;
+            int rel, yx;
+            if constexpr (KEEP) {
+                rel = prel[i];
+                yx = pyx[i];
+            } else {
+                patch_lane(i, rel, yx);
+            }
+            const bool ok = (unsigned)(sy0 + (yx & 0xffff)) < (unsigned)p.H &&
+                            (unsigned)(sx0 + (yx >> 16)) < (unsigned)p.W;
+            const char* src = ok ? origin + rel : zero;
             __builtin_amdgcn_global_load_lds((pc_gptr_t)src, (pc_lptr_t)(xl + (i * 4 + cw) * 1024),
                                              16, 0, 0);
         }
@@ -205,11 +232,10 @@ __global__ __launch_bounds__(512, 1) void conv3x3_c64_kernel(const PatchConvPara
     const int aoff = lr * 128 + ((kc ^ (lr & 7)) << 4);
     const uint32_t lds_w = (uint32_t)(uintptr_t)(pc_lptr_t)wl;     // LDS byte addresses
     const uint32_t lds_x = (uint32_t)(uintptr_t)(pc_lptr_t)xl;
-    uint32_t abase[2], abase_hi[2], bbase[3][2];
+    uint32_t abase[2], bbase[3][2];
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
         abase[kk] = lds_w + (aoff ^ (kk << 6));
-        abase_hi[kk] = abase[kk] + 65536;           // the last tap lies past the 16-bit offset field
 #pragma unroll
         for (int dx = 0; dx < 3; ++dx)
             bbase[dx][kk] = lds_x + (((cw * MT * PC_P + lr + dx) * 128 +
@@ -224,13 +250,45 @@ __global__ __launch_bounds__(512, 1) void conv3x3_c64_kernel(const PatchConvPara
     // residual of the tile being multiplied (PW): requested when its multiply starts, consumed
     // a phase later by the same waves, so the loads of BOTH groups are in flight at any time
     constexpr int NQ = PC_N3 / 32;                        // chunks of 32 output channels
-    pc_u32x4 R[PW ? NQ : 1][MT];
+    pc_u32x4 R[(PW && !PROJ) ? NQ : 1][MT];
+    // projected residual (PW 3): the block input's pixels of the tile as an MFMA operand, and
+    // three 32-channel chunks of the projection's weights at a time (chunk q in slot q % 3; a
+    // slot is refilled with chunk q + 3 as soon as chunk q has been multiplied)
+    constexpr int ADS = 3;
+    pc_u32x4 Bx[PROJ ? MT : 1][2], AD[PROJ ? ADS : 1][2][2];
+    const int wdo = (lr * 64 + kc * 8) * 2;               // this lane's byte offset in a 16-row block of wd
+    auto load_ad = [&](int q) {
+        // (the chunk's offset made opaque: one address per chunk, worked out where it is used,
+        // instead of 32 addresses kept in registers)
+        unsigned o = wdo + q * 32 * 64 * 2;
+        asm volatile("" : "+v"(o));
+        const char* base = reinterpret_cast<const char*>(p.wd) + o;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+                AD[PROJ ? q % ADS : 0][nt][kk] =
+                    *reinterpret_cast<const pc_u32x4*>(base + (nt * 16 * 64 + kk * 32) * 2);
+    };
     const int chb = ((kc & 1) * 32) + ((kc >> 1) * 16);   // lane's 16 bytes inside 64 of a pixel
     for (int f = 0; f <= n; ++f) {
         if (((f ^ g) & 1) == 0) {
             // ---- multiply tile f (if there is one)
             if (f < n) {
-                if constexpr (PW != 0) {
+                if constexpr (PROJ) {
+                    const PcTile tm = pc_tile<G::TY>(p, blockIdx.x + f * gridDim.x);
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) {
+                        const int oy = tm.y0 + cw * MT + mt, ox = tm.x0 + lr;
+                        const int cy = oy < p.H ? oy : p.H - 1, cx = ox < p.W ? ox : p.W - 1;
+                        const char* xp = reinterpret_cast<const char*>(p.x0) +
+                                         (((long)tm.b * p.H + cy) * p.W + cx) * 128 + kc * 16;
+                        Bx[mt][0] = *reinterpret_cast<const pc_u32x4*>(xp);
+                        Bx[mt][1] = *reinterpret_cast<const pc_u32x4*>(xp + 64);
+                    }
+#pragma unroll
+                    for (int q = 0; q < ADS; ++q) load_ad(q);
+                } else if constexpr (PW != 0) {
                     // A pixel outside the image reads the residual of the nearest one inside
                     // (an unconditional load keeps the queue countable).  Ordinary loads: the
                     // two 64-byte halves of a line are asked for by different instructions, and
@@ -267,9 +325,15 @@ __global__ __launch_bounds__(512, 1) void conv3x3_c64_kernel(const PatchConvPara
                         if (off < 65536)
                             asm volatile("ds_read_b128 %0, %1 offset:%2"
                                          : "=v"(qa[a]) : "v"(abase[kk]), "n"(off < 65536 ? off : 0));
-                        else
+                        else {
+                            // the last tap lies past the 16-bit offset field: its base is
+                            // made on the spot (two registers less across the whole kernel)
+                            uint32_t hi = abase[kk];
+                            asm volatile("" : "+v"(hi));
+                            hi += 65536;
                             asm volatile("ds_read_b128 %0, %1 offset:%2"
-                                         : "=v"(qa[a]) : "v"(abase_hi[kk]), "n"(off >= 65536 ? off - 65536 : 0));
+                                         : "=v"(qa[a]) : "v"(hi), "n"(off >= 65536 ? off - 65536 : 0));
+                        }
                     }
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt)
@@ -330,6 +394,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_c64_kernel(const PatchConvPara
                 asm volatile("" : "+v"(k4), "+v"(a3o0), "+v"(a3o1));
                 const float* s2p = ssl + k4;
                 const float* s3p = ssl3 + k4;
+                const float* sdp = ssld + k4;
                 const char* a3p[2] = {w3l + a3o0, w3l + a3o1};   // the two 32-channel halves
                 uint32_t P[4][MT][2];
 #pragma unroll
@@ -397,6 +462,26 @@ __global__ __launch_bounds__(512, 1) void conv3x3_c64_kernel(const PatchConvPara
                                 c3[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
                                     __builtin_bit_cast(pc_bf16x8, A3[nt][kk]),
                                     __builtin_bit_cast(pc_bf16x8, Bc[mt][kk]), c3[nt][mt], 0, 0, 0);
+                    f32x4 cd[2][MT];
+                    if constexpr (PROJ) {
+#pragma unroll
+                        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                            for (int mt = 0; mt < MT; ++mt) cd[nt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                                for (int mt = 0; mt < MT; ++mt)
+                                    cd[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                                        __builtin_bit_cast(pc_bf16x8, AD[q % ADS][nt][kk]),
+                                        __builtin_bit_cast(pc_bf16x8, Bx[mt][kk]), cd[nt][mt], 0, 0, 0);
+                        // the slot's next chunk, behind fences so that it stays here
+                        asm volatile("" ::: "memory");
+                        if (q + ADS < NQ) load_ad(q + ADS);
+                        asm volatile("" ::: "memory");
+                    }
                     const f32x4 s0 = *reinterpret_cast<const f32x4*>(s3p + q * 32);
                     const f32x4 h0 = *reinterpret_cast<const f32x4*>(s3p + PC_N3 + q * 32);
                     const f32x4 s1 = *reinterpret_cast<const f32x4*>(s3p + q * 32 + 16);
@@ -407,21 +492,39 @@ __global__ __launch_bounds__(512, 1) void conv3x3_c64_kernel(const PatchConvPara
                         // swap that builds that layout for the store takes it apart again.
                         // (Pinned here by a volatile statement: the optimiser would otherwise run
                         // the swaps right behind the load, chunks early, and wait for it there.)
-                        pc_u32x4 r = R[q][mt];
-                        asm volatile("" : "+v"(r));
-                        const pc_u32x2 ra = __builtin_amdgcn_permlane16_swap(r.x, r.z, false, false);
-                        const pc_u32x2 rb = __builtin_amdgcn_permlane16_swap(r.y, r.w, false, false);
+                        uint32_t ru[4];                 // residual: channel tile 2q (2 words), 2q+1 (2)
+                        if constexpr (PROJ) {
+                            // the projection's output as its own launch would have stored it:
+                            // scale, shift, no ReLU, rounded to bf16
+                            const f32x4 d0 = *reinterpret_cast<const f32x4*>(sdp + q * 32);
+                            const f32x4 e0 = *reinterpret_cast<const f32x4*>(sdp + PC_N3 + q * 32);
+                            const f32x4 d1 = *reinterpret_cast<const f32x4*>(sdp + q * 32 + 16);
+                            const f32x4 e1 = *reinterpret_cast<const f32x4*>(sdp + PC_N3 + q * 32 + 16);
+                            const f32x4 a = cd[0][mt], b = cd[1][mt];
+                            ru[0] = pack_bf16x2_bits(fmaf(a.x, d0.x, e0.x), fmaf(a.y, d0.y, e0.y));
+                            ru[1] = pack_bf16x2_bits(fmaf(a.z, d0.z, e0.z), fmaf(a.w, d0.w, e0.w));
+                            ru[2] = pack_bf16x2_bits(fmaf(b.x, d1.x, e1.x), fmaf(b.y, d1.y, e1.y));
+                            ru[3] = pack_bf16x2_bits(fmaf(b.z, d1.z, e1.z), fmaf(b.w, d1.w, e1.w));
+                        } else {
+                            pc_u32x4 r = R[q][mt];
+                            asm volatile("" : "+v"(r));
+                            const pc_u32x2 ra = __builtin_amdgcn_permlane16_swap(r.x, r.z, false, false);
+                            const pc_u32x2 rb = __builtin_amdgcn_permlane16_swap(r.y, r.w, false, false);
+                            ru[0] = ra.x;
+                            ru[1] = rb.x;
+                            ru[2] = ra.y;
+                            ru[3] = rb.y;
+                        }
                         const f32x4 a = c3[0][mt], b = c3[1][mt];
                         float v[8] = {fmaf(a.x, s0.x, h0.x), fmaf(a.y, s0.y, h0.y), fmaf(a.z, s0.z, h0.z),
                                       fmaf(a.w, s0.w, h0.w), fmaf(b.x, s1.x, h1.x), fmaf(b.y, s1.y, h1.y),
                                       fmaf(b.z, s1.z, h1.z), fmaf(b.w, s1.w, h1.w)};
-                        const uint32_t ru[4] = {ra.x, rb.x, ra.y, rb.y};   // tile 2q: 2 words, tile 2q+1: 2
 #pragma unroll
                         for (int i = 0; i < 4; ++i) {
                             v[2 * i] += bf16_bits_to_float(ru[i] & 0xffffu);
                             v[2 * i + 1] += bf16_bits_to_float(ru[i] >> 16);
                         }
-                        if (PW == 1) {
+                        if (PW != 2) {
 #pragma unroll
                             for (int i = 0; i < 8; ++i) v[i] = fmaxf(v[i], 0.0f);
                         }
@@ -492,14 +595,16 @@ static hipError_t pc_launch_variant(const PatchConvParams& p, unsigned nwg, hipS
 static int32_t pc_launch(const char* what, int32_t B, int32_t H, int32_t W, const void* x,
                          const void* w, const float* scale, const float* shift, int32_t relu,
                          const void* w3, const float* scale3, const float* shift3,
-                         const void* residual, int pw, void* y, pe_stream_t stream) {
+                         const void* residual, const void* x0, const void* wd, const float* scaled,
+                         const float* shiftd, int pw, void* y, pe_stream_t stream) {
     PE_REQUIRE(x && w && y, PE_E_INVALID, "%s: NULL pointer", what);
     PE_REQUIRE(B > 0 && H > 0 && W > 0, PE_E_INVALID, "%s: sizes must be positive", what);
     PE_REQUIRE(H <= 8192 && W <= 8192, PE_E_UNSUPPORTED, "%s: images above 8192 x 8192", what);
     PE_REQUIRE(relu >= 0 && relu <= 2, PE_E_INVALID, "%s: relu must be 0, 1 or 2", what);
     PE_REQUIRE(aligned(x, 16) && aligned(w, 16) && aligned(y, 16) && aligned(scale, 16) &&
                    aligned(shift, 16) && aligned(w3, 16) && aligned(scale3, 16) &&
-                   aligned(shift3, 16) && aligned(residual, 16),
+                   aligned(shift3, 16) && aligned(residual, 16) && aligned(x0, 16) &&
+                   aligned(wd, 16) && aligned(scaled, 16) && aligned(shiftd, 16),
                PE_E_INVALID, "%s: tensors must be 16-byte aligned", what);
     PatchConvParams p;
     p.x = static_cast<const uint16_t*>(x);
@@ -511,6 +616,10 @@ static int32_t pc_launch(const char* what, int32_t B, int32_t H, int32_t W, cons
     p.scale3 = scale3;
     p.shift3 = shift3;
     p.res = static_cast<const uint16_t*>(residual);
+    p.x0 = static_cast<const uint16_t*>(x0);
+    p.wd = static_cast<const uint16_t*>(wd);
+    p.scaled = scaled;
+    p.shiftd = shiftd;
     p.B = B;
     p.H = H;
     p.W = W;
@@ -536,6 +645,7 @@ static int32_t pc_launch(const char* what, int32_t B, int32_t H, int32_t W, cons
     else if (pw == 0 && affine && relu == 2) e = pc_launch_variant<2, true, 0>(p, nwg, st);
     else if (pw == 1 && affine && relu == 1) e = pc_launch_variant<1, true, 1>(p, nwg, st);
     else if (pw == 2 && affine && relu == 1) e = pc_launch_variant<1, true, 2>(p, nwg, st);
+    else if (pw == 3 && affine && relu == 1) e = pc_launch_variant<1, true, 3>(p, nwg, st);
     else launched = false;
     PE_REQUIRE(launched, PE_E_UNSUPPORTED,
                "%s: the fused pointwise layer needs scale / shift and ReLU on the 3x3 layer", what);
@@ -547,7 +657,7 @@ extern "C" int32_t pe_conv3x3_c64_fwd_bf16(int32_t B, int32_t H, int32_t W, cons
                                            const void* w, const float* scale, const float* shift,
                                            int32_t relu, void* y, pe_stream_t stream) {
     return pc_launch("pe_conv3x3_c64_fwd_bf16", B, H, W, x, w, scale, shift, relu, nullptr, nullptr,
-                     nullptr, nullptr, 0, y, stream);
+                     nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, y, stream);
 }
 
 extern "C" int32_t pe_conv3x3_c64_pw_fwd_bf16(int32_t B, int32_t H, int32_t W, const void* x,
@@ -561,6 +671,21 @@ extern "C" int32_t pe_conv3x3_c64_pw_fwd_bf16(int32_t B, int32_t H, int32_t W, c
     PE_REQUIRE(Cout3 == PC_N3, PE_E_UNSUPPORTED, "%s: the pointwise layer must have %d outputs", what,
                PC_N3);
     PE_REQUIRE(relu3 == 0 || relu3 == 1, PE_E_INVALID, "%s: relu3 must be 0 or 1", what);
-    return pc_launch(what, B, H, W, x, w, scale, shift, relu, w3, scale3, shift3, residual,
-                     relu3 ? 1 : 2, y, stream);
+    return pc_launch(what, B, H, W, x, w, scale, shift, relu, w3, scale3, shift3, residual, nullptr,
+                     nullptr, nullptr, nullptr, relu3 ? 1 : 2, y, stream);
+}
+
+extern "C" int32_t pe_conv3x3_c64_pw_proj_fwd_bf16(int32_t B, int32_t H, int32_t W, const void* x,
+                                                   const void* w, const float* scale,
+                                                   const float* shift, int32_t relu, const void* w3,
+                                                   int32_t Cout3, const float* scale3,
+                                                   const float* shift3, const void* x0,
+                                                   const void* wd, const float* scaled,
+                                                   const float* shiftd, void* y, pe_stream_t stream) {
+    const char* what = "pe_conv3x3_c64_pw_proj_fwd_bf16";
+    PE_REQUIRE(w3 && x0 && wd, PE_E_INVALID, "%s: NULL pointer", what);
+    PE_REQUIRE(Cout3 == PC_N3, PE_E_UNSUPPORTED, "%s: the pointwise layers must have %d outputs", what,
+               PC_N3);
+    return pc_launch(what, B, H, W, x, w, scale, shift, relu, w3, scale3, shift3, nullptr, x0, wd,
+                     scaled, shiftd, 3, y, stream);
 }

@@ -374,12 +374,21 @@ class PoseHRNet:
                           p[u.name + ".shift"], relu=1)
         x = self._unit(sp.stem[1], x)
         for b in sp.layer1:
-            idn = self._unit(b.down, x) if b.down else x
             c2, c3 = b.c2.name, b.c3.name
-            B, H, W, _ = x.shape
-            if (b.c2.k == 3 and b.c2.stride == 1 and b.c3.k == 1 and b.c3.stride == 1
-                    and pnn.c2c3_fusable(B, H, W, p[c2 + ".weight"], p[c3 + ".weight"],
-                                         p[c2 + ".scale"], p[c2 + ".shift"])):
+            B, H, W, C = x.shape
+            fused = (b.c2.k == 3 and b.c2.stride == 1 and b.c3.k == 1 and b.c3.stride == 1
+                     and pnn.c2c3_fusable(B, H, W, p[c2 + ".weight"], p[c3 + ".weight"],
+                                          p[c2 + ".scale"], p[c2 + ".shift"]))
+            d = b.down
+            if fused and d is not None and d.k == 1 and d.stride == 1 and C == 64 and not d.relu:
+                # conv2 + conv3 + the skip path's projection + ReLU in one launch
+                x = pnn.conv3x3_c64_pw_proj(self._unit(b.c1, x), p[c2 + ".weight"], p[c2 + ".scale"],
+                                            p[c2 + ".shift"], p[c3 + ".weight"], p[c3 + ".scale"],
+                                            p[c3 + ".shift"], x, p[d.name + ".weight"],
+                                            p[d.name + ".scale"], p[d.name + ".shift"])
+                continue
+            idn = self._unit(d, x) if d else x
+            if fused:
                 # conv2 + conv3 + residual + ReLU in one launch (bit-identical to the two)
                 x = pnn.conv3x3_c64_pw(self._unit(b.c1, x), p[c2 + ".weight"], p[c2 + ".scale"],
                                        p[c2 + ".shift"], p[c3 + ".weight"], p[c3 + ".scale"],

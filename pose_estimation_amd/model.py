@@ -299,6 +299,9 @@ class PoseResNet:
     # the layer has at least `pnn.PATCH3X3_MIN_TILES` 16 x 16 tiles (one persistent workgroup
     # per CU).  PE_RESNET_FUSE_C2C3=0 or PE_CONV_C2C3=0: two launches (comparison).
     fuse_c2c3 = os.environ.get("PE_RESNET_FUSE_C2C3", "1") != "0"
+    # ... and, in a stage's first block, the 1x1 projection of the skip path too
+    # (pe_conv3x3_c64_pw_proj_fwd_bf16).  PE_RESNET_FUSE_DOWN=0: the projection as its own launch.
+    fuse_down = os.environ.get("PE_RESNET_FUSE_DOWN", "1") != "0"
 
     def _c2c3_fusable(self, b: BlockSpec, x: torch.Tensor) -> bool:
         c1, c2, c3 = b.c1, b.c2, b.c3
@@ -339,6 +342,17 @@ class PoseResNet:
             kw = {"out": out} if (out is not None and bi == len(blocks) - 1) else {}
             if self._c2c3_fusable(b, x):
                 main = torch.cuda.current_stream(self.device)
+                if (self.fuse_down and b.down and b.down.k == 1 and b.down.stride == 1
+                        and b.down.cin == 64 and not b.down.relu):
+                    # the skip path's projection is computed inside the same launch as well:
+                    # its 256-channel tensor (403 MB at batch 256) is never written or read
+                    o1 = have_c1 if have_c1 is not None else self._conv(b.c1, x)
+                    d = b.down
+                    x = pnn.conv3x3_c64_pw_proj(o1, self.w(b.c2), self.scale[b.c2.name],
+                                                self.shift[b.c2.name], self.w(b.c3),
+                                                self.scale[b.c3.name], self.shift[b.c3.name], x,
+                                                self.w(d), self.scale[d.name], self.shift[d.name], **kw)
+                    continue
                 if b.down and side is not None:
                     side.wait_stream(main)
                     with torch.cuda.stream(side):

@@ -331,6 +331,35 @@ def conv3x3_c64_pw(x: torch.Tensor, w: torch.Tensor, scale: torch.Tensor, shift:
     return out
 
 
+def conv3x3_c64_pw_proj(x: torch.Tensor, w: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor,
+                        w3: torch.Tensor, scale3, shift3, x0: torch.Tensor, wd: torch.Tensor,
+                        scaled, shiftd, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """conv3x3_c64_pw whose residual is the pointwise projection of x0 [B,H,W,64] by wd
+    [256,1,1,64] (+ scaled, shiftd, no ReLU), computed inside the same launch
+    (pe_conv3x3_c64_pw_proj_fwd_bf16).  Equals
+    conv3x3_c64_pw(x, ..., residual=conv2d(x0, wd, scaled, shiftd)) bit for bit."""
+    _check_act(x)
+    _check_act(x0, "x0")
+    _need_gpu(w, scale, shift, w3, scale3, shift3, wd, scaled, shiftd, out)
+    B, H, W, C = x.shape
+    if C != 64 or tuple(w.shape) != (64, 3, 3, 64) or w.dtype != BF16 or not w.is_contiguous():
+        raise ValueError("conv3x3_c64_pw_proj expects x [...,64] and w contiguous bfloat16 [64,3,3,64]")
+    N3 = w3.shape[0]
+    for name, t in (("w3", w3), ("wd", wd)):
+        if t.shape[0] != N3 or t.numel() != N3 * 64 or t.dtype != BF16 or not t.is_contiguous():
+            raise ValueError(f"{name} must be contiguous bfloat16 [Cout3,1,1,64]")
+    if tuple(x0.shape) != (B, H, W, 64):
+        raise ValueError("x0 must be [B,H,W,64]")
+    if out is None:
+        out = torch.empty((B, H, W, N3), dtype=BF16, device=x.device)
+    with on_device(x):
+        check(lib().pe_conv3x3_c64_pw_proj_fwd_bf16(
+            B, H, W, x.data_ptr(), w.data_ptr(), _ptr(scale), _ptr(shift), 1, w3.data_ptr(), N3,
+            _ptr(scale3), _ptr(shift3), x0.data_ptr(), wd.data_ptr(), _ptr(scaled), _ptr(shiftd),
+            out.data_ptr(), _stream(x)))
+    return out
+
+
 def stem7x7s2_pool(x_s2d: torch.Tensor, w: torch.Tensor, scale=None, shift=None,
                    out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """stem7x7s2 (+ scale, shift, ReLU) followed by maxpool3x3s2 in one launch:

@@ -259,6 +259,29 @@ def test_conv3x3_64_channels_with_the_pointwise_layer_in_the_same_launch(case):
         assert torch.equal(goti.float().cpu(), ref)
 
 
+@pytest.mark.parametrize("case", [(2, 64, 48), (5, 16, 16), (1, 7, 5), (3, 33, 50), (300, 16, 12)])
+def test_conv3x3_pointwise_with_the_projected_residual_in_the_same_launch(case):
+    """pe_conv3x3_c64_pw_proj_fwd_bf16 (conv2 + conv3 + the projection of the skip path of a
+    stage's first bottleneck) against the three engine launches it replaces, bit for bit."""
+    B, H, W = case
+    g = torch.Generator().manual_seed(21 + H + W)
+    x = rand_bf16((B, H, W, 64), g).to(BF16).cuda()
+    x0 = rand_bf16((B, H, W, 64), g).to(BF16).cuda()
+    w = pnn.pack_conv_weight(rand_bf16((64, 64, 3, 3), g, (2.0 / 576) ** 0.5)).cuda()
+    w3 = pnn.pack_conv_weight(rand_bf16((256, 64, 1, 1), g, (2.0 / 64) ** 0.5)).cuda()
+    wd = pnn.pack_conv_weight(rand_bf16((256, 64, 1, 1), g, (2.0 / 64) ** 0.5)).cuda()
+    scale = (torch.rand(64, generator=g) + 0.5).cuda()
+    shift = (torch.randn(64, generator=g) * 0.1).cuda()
+    sc3, sh3 = (torch.rand(256, generator=g) + 0.5).cuda(), (torch.randn(256, generator=g) * 0.1).cuda()
+    scd, shd = (torch.rand(256, generator=g) + 0.5).cuda(), (torch.randn(256, generator=g) * 0.1).cuda()
+    for a3, b3, ad, bd in ((sc3, sh3, scd, shd), (None, None, None, None), (None, sh3, scd, None)):
+        idn = pnn.conv2d(x0, wd, ad, bd, None, 1, 0, False)
+        mid = pnn.conv2d(x, w, scale, shift, None, 1, 1, True)
+        want = pnn.conv2d(mid, w3, a3, b3, idn, 1, 0, True)
+        got = pnn.conv3x3_c64_pw_proj(x, w, scale, shift, w3, a3, b3, x0, wd, ad, bd)
+        assert torch.equal(got, want), (a3 is not None, ad is not None)
+
+
 def test_conv3x3_pointwise_rejects_what_it_does_not_cover():
     x = torch.zeros((1, 16, 16, 64), dtype=BF16).cuda()
     w = torch.zeros((64, 3, 3, 64), dtype=BF16).cuda()

@@ -21,7 +21,15 @@ def fused(i): pnn.conv3x3_c64_pw(x, w, s, h, w3, s3, h3, res[i & 1], True, out=o
 def sep(i):
     pnn.conv2d(x, w, s, h, None, 1, 1, True, out=mid)
     pnn.conv2d(mid, w3, s3, h3, res[i & 1], 1, 0, True, out=outs[i & 1])
-for name, fn in (("fused", fused), ("separate", sep), ("fused", fused), ("separate", sep)):
+wd = (torch.randn((256, 1, 1, 64), generator=g) * 0.17).to(BF16).cuda()
+x0 = torch.randn((B, H, W, 64), generator=g).relu().to(BF16).cuda()
+def proj(i): pnn.conv3x3_c64_pw_proj(x, w, s, h, w3, s3, h3, x0, wd, s3, h3, out=outs[i & 1])
+def sep_proj(i):
+    pnn.conv2d(x0, wd, s3, h3, None, 1, 0, False, out=res[i & 1])
+    fused(i)
+for name, fn in (("fused", fused), ("separate", sep), ("fused", fused), ("separate", sep),
+                 ("fused+projection", proj), ("projection, then fused", sep_proj),
+                 ("fused+projection", proj), ("projection, then fused", sep_proj)):
     for i in range(5): fn(i)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(True), torch.cuda.Event(True)
