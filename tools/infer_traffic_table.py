@@ -33,6 +33,14 @@ def layer_bytes(batch, H=256, W=192):
         s = b.c2.stride
         ho, wo = h // s, w // s
         out.append((b.c1.name, batch * h * w * (b.c1.cin + b.c1.cout) * 2 + b.c1.cin * b.c1.cout * 2))
+        if b.c2.cin == 64 and b.c2.cout == 64 and s == 1:
+            # conv2 + conv3 (+ the projection of the skip path) are one launch: conv2's input,
+            # the residual (or the projection's 64-channel input), the output, the weights
+            wts = (9 * 64 * 64 + 64 * b.c3.cout + (b.down.cin * b.down.cout if b.down else 0)) * 2
+            res = b.down.cin if b.down else b.c3.cout
+            out.append((b.c2.name.replace("conv2", "conv2+3") + ("+down" if b.down else ""),
+                        batch * h * w * (64 + res + b.c3.cout) * 2 + wts))
+            continue
         out.append((b.c2.name, batch * (h * w * b.c2.cin + ho * wo * b.c2.cout) * 2
                     + 9 * b.c2.cin * b.c2.cout * 2))
         if b.down:
@@ -67,13 +75,13 @@ def main():
     assert len(fetch) % n == 0 and len(write) % n == 0, (len(fetch), len(write), n)
     fetch, write = fetch[-n:], write[-n:]
     tot_t = tot_m = 0
-    print(f"{'layer':18s} {'read MB':>9s} {'written MB':>10s} {'tensor MB':>10s} {'ratio':>6s}")
+    print(f"{'layer':22s} {'read MB':>9s} {'written MB':>10s} {'tensor MB':>10s} {'ratio':>6s}")
     for (name, tb), f, w in zip(layers, fetch, write):
         rd, wr = 2 * f * 1024, w * 1024
         tot_t += tb
         tot_m += rd + wr
-        print(f"{name:18s} {rd / 1e6:9.1f} {wr / 1e6:10.1f} {tb / 1e6:10.1f} {(rd + wr) / tb:6.2f}")
-    print(f"{'forward':18s} {'':9s} {tot_m / 1e6:10.1f} {tot_t / 1e6:10.1f} {tot_m / tot_t:6.2f}")
+        print(f"{name:22s} {rd / 1e6:9.1f} {wr / 1e6:10.1f} {tb / 1e6:10.1f} {(rd + wr) / tb:6.2f}")
+    print(f"{'forward':22s} {'':9s} {tot_m / 1e6:10.1f} {tot_t / 1e6:10.1f} {tot_m / tot_t:6.2f}")
     tfile = ROOT / "profiles" / "traffic.json"
     data = json.loads(tfile.read_text())
     data[f"resnet50_pose_infer_256x192_b{batch}_bf16"] = {
@@ -82,8 +90,9 @@ def main():
         "correction": "read bytes = 2 x FETCH_SIZE x 1024 (gfx950), written = WRITE_SIZE x 1024",
         "traffic_bytes_per_launch": int(tot_m),
         "algorithmic_bytes_per_launch": int(tot_t),
-        "note": "per step; tensor bytes = every layer's input + output (+ residual) + weights once; "
-                "stem and max pool are one launch (the stem's own map is never written)",
+        "note": "per step; tensor bytes = every launch's input + output (+ residual) + weights once; "
+                "stem + max pool, and conv2 + conv3 (+ skip projection) of layer1's bottlenecks, are "
+                "one launch each (the tensors between them are never written)",
         "round": 3,
     }
     tfile.write_text(json.dumps(data, indent=1) + "\n")
