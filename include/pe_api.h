@@ -352,6 +352,17 @@ int32_t pe_conv3x3_c64_fwd_bf16(int32_t B, int32_t H, int32_t W, const void* x, 
                                 const float* scale, const float* shift, int32_t relu, void* y,
                                 pe_stream_t stream);
 
+/* The 32-channel twin: 3x3 stride-1 pad-1 conv with 32 input and 32 output channels (+ scale,
+ * shift, residual, relu as in pe_conv2d_fwd_bf16), x, residual, y [B,H,W,32] bf16 NHWC, w in
+ * the narrow packing [32][3][2][64] that pe_conv2d_fwd_bf16 takes for 32 input channels: the
+ * 3x3 layers of the highest-resolution branch of a multi-branch backbone (nets/*.py,
+ * PoseEstimation.pyproj:31-32; absent) for inference.  Persistent workgroups with the whole
+ * filter in LDS (60 KB per workgroup: they share a CU with other launches).  H, W <= 8192.
+ * Equals pe_conv2d_fwd_bf16 on the same operands bit for bit. */
+int32_t pe_conv3x3_c32_fwd_bf16(int32_t B, int32_t H, int32_t W, const void* x,
+                                const void* w_narrow, const float* scale, const float* shift,
+                                const void* residual, int32_t relu, void* y, pe_stream_t stream);
+
 /* The same 3x3 layer followed, in the same launch, by the pointwise (1x1) layer that reads it:
  * y = act3( conv1x1( bf16( act(conv3x3(x, w) * scale + shift) ), w3 ) * scale3 + shift3 + residual ),
  * w3 [Cout3][64] bf16, scale3 / shift3 [Cout3] float32 (NULL = 1 / 0), residual and y

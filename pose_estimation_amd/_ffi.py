@@ -196,6 +196,8 @@ SIGNATURES = {
                   c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "pe_conv3x3_c64_fwd_bf16": (
         c_int32, [c_int32] * 3 + [c_void_p] * 4 + [c_int32, c_void_p, c_void_p]),
+    "pe_conv3x3_c32_fwd_bf16": (
+        c_int32, [c_int32] * 3 + [c_void_p] * 5 + [c_int32, c_void_p, c_void_p]),
     "pe_conv3x3_c64_pw_fwd_bf16": (
         c_int32, [c_int32] * 3 + [c_void_p] * 4 + [c_int32, c_void_p, c_int32] + [c_void_p] * 3
         + [c_int32, c_void_p, c_void_p]),

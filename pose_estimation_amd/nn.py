@@ -100,6 +100,11 @@ def _check_act(x: torch.Tensor, name: str = "x"):
 # with the threshold at 128 tiles the HRNet-style forward, whose 64-channel branch has 576, went
 # from 5.65 to 6.03 ms.  PE_CONV_PATCH3X3=0: always the engine (comparison).
 PATCH3X3 = os.environ.get("PE_CONV_PATCH3X3", "1") != "0"
+# The 32-channel twin (pe_conv3x3_c32_fwd_bf16: 3x3 stride-1 pad-1, 32 -> 32 channels, residual
+# allowed) needs 60 KB of LDS, so it shares a CU with other streams' launches.
+# PE_CONV_PATCH3X3_C32=0: always the engine.
+PATCH3X3_C32 = os.environ.get("PE_CONV_PATCH3X3_C32", "1") != "0"
+PATCH3X3_C32_MIN_TILES = int(os.environ.get("PE_CONV_PATCH3X3_C32_MIN_TILES", "512"))
 PATCH3X3_MIN_TILES = int(os.environ.get("PE_CONV_PATCH3X3_MIN_TILES", "1024"))
 
 
@@ -129,6 +134,10 @@ def conv2d(x: torch.Tensor, w: torch.Tensor, scale: Optional[torch.Tensor] = Non
             and residual is None and not out_f32_nchw
             and B * ((H + 15) // 16) * ((W + 15) // 16) >= PATCH3X3_MIN_TILES):
         return conv3x3_c64(x, w, scale, shift, int(relu), out)
+    if (PATCH3X3_C32 and Cin == 32 and Cout == 32 and KH == 3 and KW == 3 and stride == 1
+            and pad == 1 and not out_f32_nchw
+            and B * ((H + 15) // 16) * ((W + 15) // 16) >= PATCH3X3_C32_MIN_TILES):
+        return conv3x3_c32(x, w, scale, shift, residual, int(relu), out)
     if out is None:
         if out_f32_nchw:
             out = torch.empty((B, Cout, Ho, Wo), dtype=torch.float32, device=x.device)
@@ -301,6 +310,30 @@ def c2c3_fusable(B: int, H: int, W: int, w2: torch.Tensor, w3: torch.Tensor, sca
     return (C2C3 and tuple(w2.shape) == (64, 3, 3, 64) and w3.shape[0] == 256
             and w3.numel() == 256 * 64 and scale2 is not None and shift2 is not None
             and B * ((H + 15) // 16) * ((W + 15) // 16) >= PATCH3X3_MIN_TILES)
+
+
+def conv3x3_c32(x: torch.Tensor, w_narrow: torch.Tensor, scale=None, shift=None, residual=None,
+                relu: int = 1, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """3x3 stride-1 pad-1 conv, 32 -> 32 channels (+ scale, shift, residual, ReLU), through the
+    resident-filter kernel (pe_conv3x3_c32_fwd_bf16); w_narrow is pack_conv_weight_narrow's
+    [32,3,2,64].  Equals conv2d(x, w_narrow, scale, shift, residual, 1, 1, relu, kw=3) bit for
+    bit."""
+    _check_act(x)
+    _need_gpu(w_narrow, scale, shift, residual, out)
+    B, H, W, C = x.shape
+    if (C != 32 or tuple(w_narrow.shape) != (32, 3, 2, 64) or w_narrow.dtype != BF16
+            or not w_narrow.is_contiguous()):
+        raise ValueError("conv3x3_c32 expects x [...,32] and w contiguous bfloat16 [32,3,2,64]")
+    if residual is not None and (tuple(residual.shape) != (B, H, W, 32) or residual.dtype != BF16
+                                 or not residual.is_contiguous()):
+        raise ValueError("residual must be contiguous bfloat16 [B,H,W,32]")
+    if out is None:
+        out = torch.empty((B, H, W, 32), dtype=BF16, device=x.device)
+    with on_device(x):
+        check(lib().pe_conv3x3_c32_fwd_bf16(B, H, W, x.data_ptr(), w_narrow.data_ptr(), _ptr(scale),
+                                            _ptr(shift), _ptr(residual), int(relu), out.data_ptr(),
+                                            _stream(x)))
+    return out
 
 
 def conv3x3_c64_pw(x: torch.Tensor, w: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor,

@@ -8,6 +8,7 @@ Two kinds of comparison:
   * random bf16 operands with the tolerance |got - ref| <= 4e-3 * max|ref| (one bf16 rounding
     of the result is 2^-9 relative; fp32 accumulation-order noise is far below that).
 """
+import ctypes
 import os
 
 import numpy as np
@@ -222,6 +223,36 @@ def test_conv3x3_64_channels_resident_filter_kernel(case):
         wi = int_tensor((64, 64, 3, 3), g, -1, 1)
         ref = to.bf16r(to.conv2d(xi, wi, stride=1, pad=1))
         goti = pnn.conv3x3_c64(xi.to(BF16).cuda(), pnn.pack_conv_weight(wi).cuda(), relu=0)
+        assert torch.equal(goti.float().cpu(), ref)
+
+
+@pytest.mark.parametrize("case", [(2, 96, 72), (5, 16, 16), (1, 7, 5), (3, 33, 50), (300, 16, 12)])
+def test_conv3x3_32_channels_resident_filter_kernel(case):
+    """pe_conv3x3_c32_fwd_bf16 against the engine on the same operands (narrow weight packing),
+    bit for bit, with and without scale / shift, residual and the activations; exact against
+    the oracle on integer operands."""
+    B, H, W = case
+    g = torch.Generator().manual_seed(31 + H + W)
+    x = rand_bf16((B, H, W, 32), g).to(BF16).cuda()
+    w = rand_bf16((32, 32, 3, 3), g, (2.0 / 288) ** 0.5)
+    wp = pnn.pack_conv_weight_narrow(w).cuda()
+    scale = (torch.rand(32, generator=g) + 0.5).cuda()
+    shift = (torch.randn(32, generator=g) * 0.1).cuda()
+    res = rand_bf16((B, H, W, 32), g).to(BF16).cuda()
+    for sc, sh, r, relu in ((scale, shift, None, 1), (scale, shift, res, 1), (None, None, res, 0),
+                            (None, shift, None, 2), (None, None, None, 0)):
+        got = pnn.conv3x3_c32(x, wp, sc, sh, r, relu)
+        d = pnn.ConvDesc(B, H, W, 32, 32, 3, 3, 1, 1, relu, 0)
+        want = torch.empty_like(got)
+        pnn.check(pnn.lib().pe_conv2d_fwd_bf16(ctypes.addressof(d), x.data_ptr(), wp.data_ptr(),
+                                               pnn._ptr(sc), pnn._ptr(sh), pnn._ptr(r),
+                                               want.data_ptr(), pnn._stream(x)))
+        assert torch.equal(got, want), (sc is not None, r is not None, relu)
+    if B <= 5:
+        xi = int_tensor((B, H, W, 32), g, -2, 2)
+        wi = int_tensor((32, 32, 3, 3), g, -1, 1)
+        ref = to.bf16r(to.conv2d(xi, wi, stride=1, pad=1))
+        goti = pnn.conv3x3_c32(xi.to(BF16).cuda(), pnn.pack_conv_weight_narrow(wi).cuda(), relu=0)
         assert torch.equal(goti.float().cpu(), ref)
 
 
