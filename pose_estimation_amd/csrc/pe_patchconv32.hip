@@ -219,7 +219,14 @@ __global__ __launch_bounds__(512, 1) void conv3x3_c32_kernel(const Patch32Params
             // every read of the patch has returned before the barrier frees the buffer
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         } else if (f >= 1) {
-            // ---- finish tile f - 1: next patch first (the loads fly under the conversion)
+            // ---- finish tile f - 1.  The residual, requested a phase ago, is waited for HERE,
+            // before the next patch is requested: waited for at its first use further down, the
+            // compiler's vmcnt(0) would also wait for that patch.
+            if constexpr (RES) {
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) asm volatile("" : "+v"(R[mt]));
+            }
+            // next patch first (the loads fly under the conversion)
             issue_patch(blockIdx.x + (f + 1) * gridDim.x);
             const P32Tile tl = p32_tile(p, blockIdx.x + (f - 1) * gridDim.x);
             const f32x4 sc0 = *reinterpret_cast<const f32x4*>(ssl + kc * 4);
