@@ -319,7 +319,7 @@ class Infer(Workload):
     batch = 256
     dtype = "bf16"
     bound = "mfma"
-    kernel = "igemm_kernel (all conv/deconv launches of one forward)"
+    kernel = "igemm_kernel + stem_pool_kernel + conv3x3_c64_kernel (all conv/deconv launches of one forward)"
     peak = 2500.0  # dense bf16 MFMA, TFLOP/s
 
     def setup(self, device):
@@ -428,7 +428,7 @@ class HRNetInfer(Workload):
     heatmap = (96, 72)
     dtype = "bf16"
     bound = "mfma"
-    kernel = "igemm_kernel + fuse_upsample_add_kernel (all launches of one forward)"
+    kernel = "igemm_kernel + conv3x3_c32_kernel + conv3x3_c64_kernel + fuse_upsample_add_kernel (all launches of one forward)"
     peak = 2500.0
 
     def setup(self, device):
