@@ -394,6 +394,25 @@ int32_t pe_conv3x3_c64_pw_proj_fwd_bf16(int32_t B, int32_t H, int32_t W, const v
                                         const void* wd, const float* scaled, const float* shiftd,
                                         void* y, pe_stream_t stream);
 
+/* pe_conv3x3_c64_pw_fwd_bf16 (relu3 = 1) for a bottleneck that is FOLLOWED by another one of the
+ * same stage: the launch also computes the next block's first pointwise layer on the tile it
+ * has just finished,
+ * y_next = relu( conv1x1(y, w_next) * scale_next + shift_next ),
+ * w_next [Cout_next][Cout3] bf16, scale_next / shift_next [Cout_next] float32 (NULL = 1 / 0),
+ * y_next [B,H,W,Cout_next] bf16 (conv1 of the next bottleneck, nets/mobilenet_v2.py,
+ * PoseEstimation.pyproj:32; absent).  y is written as before (the next block adds it back as
+ * its residual) but not read again: each 32-channel chunk of a finished tile, rounded to bf16
+ * as stored, is one K step of the next layer while it is still in registers.  Cout3 must be 256
+ * and Cout_next 64; otherwise as pe_conv3x3_c64_pw_fwd_bf16.  Equals that call followed by
+ * pe_conv2d_fwd_bf16(1x1, relu) on y bit for bit. */
+int32_t pe_conv3x3_c64_pw_next_fwd_bf16(int32_t B, int32_t H, int32_t W, const void* x,
+                                        const void* w, const float* scale, const float* shift,
+                                        int32_t relu, const void* w3, int32_t Cout3,
+                                        const float* scale3, const float* shift3,
+                                        const void* residual, void* y, const void* w_next,
+                                        int32_t Cout_next, const float* scale_next,
+                                        const float* shift_next, void* y_next, pe_stream_t stream);
+
 /* 3x3 stride-2 pad-1 stem on a 3-channel image (MobileNetV2's first conv; the reference's
  * backbone, nets/mobilenet_v2.py, PoseEstimation.pyproj:32, absent), computed over the same
  * space-to-depth image as a 2-row conv: w [Cout][2 rows][4 cols x 16] bf16 (columns 2, 3 zero),

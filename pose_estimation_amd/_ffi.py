@@ -203,6 +203,9 @@ SIGNATURES = {
         + [c_int32, c_void_p, c_void_p]),
     "pe_conv3x3_c64_pw_proj_fwd_bf16": (
         c_int32, [c_int32] * 3 + [c_void_p] * 4 + [c_int32, c_void_p, c_int32] + [c_void_p] * 8),
+    "pe_conv3x3_c64_pw_next_fwd_bf16": (
+        c_int32, [c_int32] * 3 + [c_void_p] * 4 + [c_int32, c_void_p, c_int32] + [c_void_p] * 5
+        + [c_int32] + [c_void_p] * 4),
     "pe_stem7x7s2_pool_fwd_bf16": (
         c_int32, [c_int32] * 4 + [c_void_p] * 6),
     "pe_deconv4x4s2_head_fwd_bf16": (

@@ -50,21 +50,34 @@ constexpr int PC_P = PC_TX + 2;                   // patch width
 constexpr int PC_WBYTES = 9 * 64 * 128;           // 73 728: the 3x3 filter
 constexpr int PC_N3 = 256;                        // output channels of the fused pointwise layer
 constexpr int PC_W3BYTES = PC_N3 * 128;           // 32 768: its weights
+constexpr int PC_W1BYTES = 64 * PC_N3 * 2;        // 32 768: the next block's 256 -> 64 layer
 
 // Geometry of a variant.  Alone, the 3x3 layer works on 16 x 16 tiles (4 rows per wave).  With
 // the pointwise layer the tile is 8 rows high (2 rows per wave): its smaller patch buffers make
 // room for the pointwise weights in LDS, and a wave's share of the 256-channel output (32 pixels)
 // leaves registers for residual loads several chunks ahead.
+//
+// With the NEXT block's first pointwise layer (256 -> 64) in the same launch as well (PW 4) its
+// weights take another 32 KB of LDS.  That leaves room for ONE patch buffer of a 4-row tile (one
+// row per wave), shared by the two groups: a phase then has a second barrier, behind the
+// multiplying group's last read of the buffer, after which the other group requests the patch
+// it multiplies in the next phase (the multiply is a small part of such a phase; the rest of
+// it belongs to the finishing group's loads and stores).
 template <int PW>
 struct PcGeo {
-    static constexpr int TY = PW ? 8 : 16;            // output tile height
+    static constexpr bool NEXT = PW >= 4;
+    static constexpr bool PROJ = PW == 3;
+    static constexpr int TY = NEXT ? 4 : PW ? 8 : 16; // output tile height
     static constexpr int MT = TY / 4;                 // 16-pixel rows per wave
-    static constexpr int NPIX = (TY + 2) * PC_P;      // patch pixels: 324 / 180
-    static constexpr int NINSTR = (NPIX + 7) / 8;     // wave instructions of 8 pixels: 41 / 23
-    static constexpr int XBYTES = NINSTR * 1024;      // per patch buffer: 41 984 / 23 552
+    static constexpr int NBUF = NEXT ? 1 : 2;         // patch buffers
+    static constexpr int NPIX = (TY + 2) * PC_P;      // patch pixels: 324 / 180 / 108
+    static constexpr int NINSTR = (NPIX + 7) / 8;     // wave instructions of 8 pixels: 41 / 23 / 14
+    static constexpr int XBYTES = NINSTR * 1024;      // per patch buffer: 41 984 / 23 552 / 14 336
     static constexpr int W3B = PW ? PC_W3BYTES : 0;
-    static constexpr int LDS = PC_WBYTES + W3B + 2 * XBYTES + 2 * 64 * 4 + (PW ? 2 * PC_N3 * 4 : 0) +
-                               (PW == 3 ? 2 * PC_N3 * 4 : 0);
+    static constexpr int W1B = NEXT ? PC_W1BYTES : 0;
+    static constexpr int LDS = PC_WBYTES + W3B + W1B + NBUF * XBYTES + 2 * 64 * 4 +
+                               (PW ? 2 * PC_N3 * 4 : 0) + (PROJ ? 2 * PC_N3 * 4 : 0) +
+                               (NEXT ? 2 * 64 * 4 : 0);
 };
 
 __device__ __attribute__((aligned(16))) uint32_t g_pc_zero16[4] = {0u, 0u, 0u, 0u};
@@ -86,6 +99,10 @@ struct PatchConvParams {
     const uint16_t* wd;    // projection's weights [256][64] and its scale / shift [256]
     const float* scaled;
     const float* shiftd;
+    const uint16_t* w1;    // the next block's first pointwise layer (PW 4): weights [64][256],
+    const float* scale1;   // scale / shift [64] (ReLU behind them) and its output
+    const float* shift1;   // [B][H][W][64]
+    uint16_t* z;
     int B, H, W;
     int tiles_x, tiles_y, ntiles;
 };
@@ -125,11 +142,14 @@ __global__ __launch_bounds__(512, 1) void conv3x3_c64_kernel(const PatchConvPara
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* wl = smem;                                      // 3x3 filter
     char* w3l = smem + PC_WBYTES;                         // pointwise weights (PW only)
-    char* const xb0 = smem + PC_WBYTES + G::W3B;          // two patch buffers
-    float* ssl = reinterpret_cast<float*>(xb0 + 2 * G::XBYTES);
+    char* w1l = smem + PC_WBYTES + G::W3B;                // the next block's pointwise weights (NEXT)
+    char* const xb0 = smem + PC_WBYTES + G::W3B + G::W1B; // the patch buffer(s)
+    float* ssl = reinterpret_cast<float*>(xb0 + G::NBUF * G::XBYTES);
     float* ssl3 = ssl + 128;
     float* ssld = ssl3 + 2 * PC_N3;                       // PW 3 only
-    constexpr bool PROJ = PW == 3;
+    constexpr bool PROJ = G::PROJ;
+    constexpr bool NEXT = G::NEXT;
+    float* ssl1 = ssld + (PROJ ? 2 * PC_N3 : 0);          // NEXT only
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -137,7 +157,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_c64_kernel(const PatchConvPara
     const int g = wid >> 2;                               // group: 0 or 1
     const int cw = wid & 3;                               // wave inside the group
     const int lr = lane & 15, kc = lane >> 4;
-    char* const xl = xb0 + g * G::XBYTES;                 // this group's patch buffer
+    char* const xl = xb0 + (G::NBUF == 2 ? g : 0) * G::XBYTES;   // this group's patch buffer
 
     // ---- weights: rows of 128 bytes; lane l of a wave instruction -> row l>>3, slot l&7, which
     // receives channel chunk (l & 7) ^ (row & 7)
@@ -159,6 +179,21 @@ __global__ __launch_bounds__(512, 1) void conv3x3_c64_kernel(const PatchConvPara
                     (pc_gptr_t)src, (pc_lptr_t)(w3l + (i * 64 + 8 * wid) * 128), 16, 0, 0);
             }
         }
+        if constexpr (NEXT) {
+            // Eight planes, one per 32-channel K step, of 64 rows (output channels) x 64 bytes;
+            // a wave instruction fills 16 rows: lane l -> row l >> 2, slot l & 3, which receives
+            // channel chunk (l & 3) ^ ((row >> 1) & 3) (conflict-free fragment reads, as the
+            // filter rows of pe_patchconv32.hip).
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int blk = i * 8 + wid;              // 0..31: plane blk >> 2, rows 16 (blk & 3) ..
+                const int row = (blk & 3) * 16 + (lane >> 2);
+                const int c = (lane & 3) ^ ((row >> 1) & 3);
+                const uint16_t* src = p.w1 + row * PC_N3 + (blk >> 2) * 32 + c * 8;
+                __builtin_amdgcn_global_load_lds((pc_gptr_t)src, (pc_lptr_t)(w1l + blk * 1024), 16,
+                                                 0, 0);
+            }
+        }
     }
     if (tid < 64) {
         ssl[tid] = p.scale ? p.scale[tid] : 1.0f;
@@ -172,6 +207,10 @@ __global__ __launch_bounds__(512, 1) void conv3x3_c64_kernel(const PatchConvPara
             ssld[PC_N3 + tid] = p.shiftd ? p.shiftd[tid] : 0.0f;
         }
     }
+    if (NEXT && tid < 64) {
+        ssl1[tid] = p.scale1 ? p.scale1[tid] : 1.0f;
+        ssl1[64 + tid] = p.shift1 ? p.shift1[tid] : 0.0f;
+    }
     // tiles of this workgroup: blockIdx.x + k * gridDim.x, k = 0 .. n - 1; group g takes k = g mod 2
     const int n = (p.ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
 
@@ -182,7 +221,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_c64_kernel(const PatchConvPara
     // instead (a spilled value would be worse than both: its reload is a vector memory
     // operation, and waiting for it drains every load and store in flight).
     constexpr int NB = (G::NINSTR + 3) / 4;               // 11 / 6
-    constexpr bool KEEP = PW != 3;
+    constexpr bool KEEP = !PROJ;
     int prel[KEEP ? NB : 1], pyx[KEEP ? NB : 1];
     auto patch_lane = [&](int i, int& rel, int& yx) {
         int ln = lane;
@@ -221,7 +260,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_c64_kernel(const PatchConvPara
                                              16, 0, 0);
         }
     };
-    issue_patch(blockIdx.x + g * gridDim.x);              // tile k = g (or none)
+    // tile k = g (or none); with one shared buffer group 1 asks for its first patch in phase 0
+    if (!NEXT || g == 0) issue_patch(blockIdx.x + g * gridDim.x);
 
     // Fragment addresses, all of the per-lane part worked out once: a K step then issues its
     // LDS reads with immediate offsets and no vector arithmetic (one wave per SIMD multiplies,
@@ -250,6 +290,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_c64_kernel(const PatchConvPara
     // residual of the tile being multiplied (PW): requested when its multiply starts, consumed
     // a phase later by the same waves, so the loads of BOTH groups are in flight at any time
     constexpr int NQ = PC_N3 / 32;                        // chunks of 32 output channels
+    constexpr int QMID = 2;                               // NEXT: chunks finished before the shared
+                                                          // buffer is asked for again
     pc_u32x4 R[(PW && !PROJ) ? NQ : 1][MT];
     // projected residual (PW 3): the block input's pixels of the tile as an MFMA operand, and
     // three 32-channel chunks of the projection's weights at a time (chunk q in slot q % 3; a
@@ -356,7 +398,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_c64_kernel(const PatchConvPara
                             asm volatile("s_waitcnt lgkmcnt(0)"
                                          : "+v"(qa[0]), "+v"(qa[1]), "+v"(qa[2]), "+v"(qa[3]),
                                            "+v"(qb[0]), "+v"(qb[1]), "+v"(qb[2]), "+v"(qb[3]));
-                    } else {
+                    } else if constexpr (MT == 2) {
                         if (s + 1 < 18)
                             asm volatile("s_waitcnt lgkmcnt(6)"
                                          : "+v"(qa[0]), "+v"(qa[1]), "+v"(qa[2]), "+v"(qa[3]),
@@ -365,6 +407,15 @@ __global__ __launch_bounds__(512, 1) void conv3x3_c64_kernel(const PatchConvPara
                             asm volatile("s_waitcnt lgkmcnt(0)"
                                          : "+v"(qa[0]), "+v"(qa[1]), "+v"(qa[2]), "+v"(qa[3]),
                                            "+v"(qb[0]), "+v"(qb[1]));
+                    } else {
+                        if (s + 1 < 18)
+                            asm volatile("s_waitcnt lgkmcnt(5)"
+                                         : "+v"(qa[0]), "+v"(qa[1]), "+v"(qa[2]), "+v"(qa[3]),
+                                           "+v"(qb[0]));
+                        else
+                            asm volatile("s_waitcnt lgkmcnt(0)"
+                                         : "+v"(qa[0]), "+v"(qa[1]), "+v"(qa[2]), "+v"(qa[3]),
+                                           "+v"(qb[0]));
                     }
 #pragma unroll
                     for (int a = 0; a < 4; ++a)
@@ -377,9 +428,20 @@ __global__ __launch_bounds__(512, 1) void conv3x3_c64_kernel(const PatchConvPara
             }
             // every read of the patch has returned before the barrier frees the buffer
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        } else if (f >= 1) {
-            // ---- finish tile f - 1: next patch first (the loads fly under the conversion)
+            if constexpr (NEXT) {
+                __builtin_amdgcn_s_barrier();             // the shared buffer is free from here
+                asm volatile("" ::: "memory");
+            }
+        } else if (NEXT && f == 0) {
+            // shared buffer: this group's first patch, behind the other group's first multiply
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
             issue_patch(blockIdx.x + (f + 1) * gridDim.x);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else if (f >= 1) {
+            // ---- finish tile f - 1: next patch first (the loads fly under the conversion); with
+            // the shared buffer, behind the barrier in the chunk loop below
+            if constexpr (!NEXT) issue_patch(blockIdx.x + (f + 1) * gridDim.x);
             const PcTile tl = pc_tile<G::TY>(p, blockIdx.x + (f - 1) * gridDim.x);
             const bool full = tl.y0 + G::TY <= p.H && tl.x0 + PC_TX <= p.W;
             if constexpr (PW != 0) {
@@ -438,16 +500,86 @@ __global__ __launch_bounds__(512, 1) void conv3x3_c64_kernel(const PatchConvPara
                                       ((((long)tl.b * p.H + oy) * p.W + ox) * (PC_N3 * 2) + chb)
                                 : reinterpret_cast<char*>(g_pc_sink) + lane * 16;
                 }
+                f32x4 acc1[4][MT];                        // the next block's 64-channel tile (NEXT)
+                if constexpr (NEXT) {
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt) acc1[nt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+                // NEXT: one wave per SIMD works through the chunks, so an LDS round trip it
+                // waits for is lost time.  What chunk q + 1 reads from LDS (pointwise weights,
+                // scale / shift rows, the next layer's weights: 12 reads) is requested at the
+                // top of chunk q into a second set of registers and waited for at the top of
+                // chunk q + 1, when nothing younger is in the queue.  Inline assembly, for the
+                // reason given at the K loop.
+                constexpr bool PFT = NEXT;
+                pc_u32x4 LA3[NEXT ? 2 : 1][2][2], LT[PFT ? 2 : 1][4], LA1[NEXT ? 2 : 1][4];
+                uint32_t a3b[2], tb, a1b;
+                if constexpr (NEXT) {
+                    a3b[0] = lds_w + PC_WBYTES + a3o0;
+                    a3b[1] = lds_w + PC_WBYTES + a3o1;
+                    tb = (uint32_t)(uintptr_t)(pc_lptr_t)ssl3 + k4 * 4;
+                    a1b = (uint32_t)(uintptr_t)(pc_lptr_t)w1l + (lr * 64) + ((kc ^ ((lr >> 1) & 3)) << 4);
+                }
+                auto load_chunk = [&](int q, pc_u32x4(&A3)[2][2], pc_u32x4(&T)[4], pc_u32x4(&A1)[4]) {
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                        for (int kk = 0; kk < 2; ++kk)
+                            asm volatile("ds_read_b128 %0, %1 offset:%2"
+                                         : "=v"(A3[nt][kk]) : "v"(a3b[kk]), "n"((q * 32 + nt * 16) * 128));
+                    if constexpr (PFT) {
+                        // scale, shift of channel tile 2 q, then of tile 2 q + 1
+                        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(T[0]) : "v"(tb), "n"(q * 128));
+                        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(T[1]) : "v"(tb), "n"(PC_N3 * 4 + q * 128));
+                        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(T[2]) : "v"(tb), "n"(q * 128 + 64));
+                        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(T[3]) : "v"(tb), "n"(PC_N3 * 4 + q * 128 + 64));
+                    }
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt)
+                        asm volatile("ds_read_b128 %0, %1 offset:%2"
+                                     : "=v"(A1[nt]) : "v"(a1b), "n"(q * 4096 + nt * 1024));
+                };
+                if constexpr (NEXT) load_chunk(0, LA3[0], LT[0], LA1[0]);
+                constexpr int TS = PFT ? 1 : 0;           // LT's slot mask
+
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) {
+                    const int cur = NEXT ? (q & 1) : 0;
+                    if constexpr (NEXT) {
+                        if constexpr (PFT)
+                            asm volatile("s_waitcnt lgkmcnt(0)"
+                                         : "+v"(LA3[cur][0][0]), "+v"(LA3[cur][0][1]), "+v"(LA3[cur][1][0]),
+                                           "+v"(LA3[cur][1][1]), "+v"(LT[cur][0]), "+v"(LT[cur][1]),
+                                           "+v"(LT[cur][2]), "+v"(LT[cur][3]), "+v"(LA1[cur][0]),
+                                           "+v"(LA1[cur][1]), "+v"(LA1[cur][2]), "+v"(LA1[cur][3]));
+                        else
+                            asm volatile("s_waitcnt lgkmcnt(0)"
+                                         : "+v"(LA3[cur][0][0]), "+v"(LA3[cur][0][1]), "+v"(LA3[cur][1][0]),
+                                           "+v"(LA3[cur][1][1]), "+v"(LA1[cur][0]), "+v"(LA1[cur][1]),
+                                           "+v"(LA1[cur][2]), "+v"(LA1[cur][3]));
+                        if (q == QMID) {
+                            // the other group has finished reading the shared patch buffer
+                            __builtin_amdgcn_s_barrier();
+                            asm volatile("" ::: "memory");
+                            issue_patch(blockIdx.x + (f + 1) * gridDim.x);
+                        }
+                        if (q + 1 < NQ)
+                            load_chunk(q + 1, LA3[(q + 1) & 1], LT[(q + 1) & TS], LA1[(q + 1) & 1]);
+                    }
                     // the chunk's weights: rows 32 q .. + 31 of the pointwise filter, from LDS
                     pc_u32x4 A3[2][2];
 #pragma unroll
                     for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-                        for (int kk = 0; kk < 2; ++kk)
-                            A3[nt][kk] = *reinterpret_cast<const pc_u32x4*>(
-                                a3p[kk] + (q * 32 + nt * 16) * 128);
+                        for (int kk = 0; kk < 2; ++kk) {
+                            if constexpr (NEXT)
+                                A3[nt][kk] = LA3[cur][nt][kk];
+                            else
+                                A3[nt][kk] = *reinterpret_cast<const pc_u32x4*>(
+                                    a3p[kk] + (q * 32 + nt * 16) * 128);
+                        }
                     f32x4 c3[2][MT];
 #pragma unroll
                     for (int nt = 0; nt < 2; ++nt)
@@ -482,10 +614,18 @@ __global__ __launch_bounds__(512, 1) void conv3x3_c64_kernel(const PatchConvPara
                         if (q + ADS < NQ) load_ad(q + ADS);
                         asm volatile("" ::: "memory");
                     }
-                    const f32x4 s0 = *reinterpret_cast<const f32x4*>(s3p + q * 32);
-                    const f32x4 h0 = *reinterpret_cast<const f32x4*>(s3p + PC_N3 + q * 32);
-                    const f32x4 s1 = *reinterpret_cast<const f32x4*>(s3p + q * 32 + 16);
-                    const f32x4 h1 = *reinterpret_cast<const f32x4*>(s3p + PC_N3 + q * 32 + 16);
+                    f32x4 s0, h0, s1, h1;
+                    if constexpr (PFT) {
+                        s0 = __builtin_bit_cast(f32x4, LT[cur][0]);
+                        h0 = __builtin_bit_cast(f32x4, LT[cur][1]);
+                        s1 = __builtin_bit_cast(f32x4, LT[cur][2]);
+                        h1 = __builtin_bit_cast(f32x4, LT[cur][3]);
+                    } else {
+                        s0 = *reinterpret_cast<const f32x4*>(s3p + q * 32);
+                        h0 = *reinterpret_cast<const f32x4*>(s3p + PC_N3 + q * 32);
+                        s1 = *reinterpret_cast<const f32x4*>(s3p + q * 32 + 16);
+                        h1 = *reinterpret_cast<const f32x4*>(s3p + PC_N3 + q * 32 + 16);
+                    }
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt) {
                         // The residual arrives as 8 contiguous channels per lane; the same row
@@ -534,12 +674,61 @@ __global__ __launch_bounds__(512, 1) void conv3x3_c64_kernel(const PatchConvPara
                         const pc_u32x2 o1 = __builtin_amdgcn_permlane16_swap(x1, y1, false, false);
                         const pc_u32x4 o = {o0.x, o1.x, o0.y, o1.y};
                         *reinterpret_cast<pc_u32x4*>(yp[mt] + q * 64) = o;
+                        if constexpr (NEXT) {
+                            // The chunk just made (32 of the 256 channels, rounded to bf16 as
+                            // stored) is K step q of the next block's pointwise layer: the same
+                            // two row swaps as above turn it into that layer's activation operand.
+                            pc_u32x4 Bn;
+                            {
+                                const pc_u32x2 t0 = __builtin_amdgcn_permlane32_swap(x0, y0, false, false);
+                                const pc_u32x2 u0 = __builtin_amdgcn_permlane16_swap(t0.x, t0.y, false, false);
+                                const pc_u32x2 t1 = __builtin_amdgcn_permlane32_swap(x1, y1, false, false);
+                                const pc_u32x2 u1 = __builtin_amdgcn_permlane16_swap(t1.x, t1.y, false, false);
+                                Bn = pc_u32x4{u0.x, u1.x, u0.y, u1.y};
+                            }
+#pragma unroll
+                            for (int nt = 0; nt < 4; ++nt)
+                                acc1[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                                    __builtin_bit_cast(pc_bf16x8, LA1[cur][nt]),
+                                    __builtin_bit_cast(pc_bf16x8, Bn), acc1[nt][mt], 0, 0, 0);
+                        }
                     }
                 }
-                // The patch requests are older than this tile's NQ * MT stores, every one of
-                // which was issued (to the image or to the sink), and vector memory operations
-                // retire in order: "all but NQ * MT" means the patch has landed.
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NQ * MT) : "memory");
+                if constexpr (NEXT) {
+                    // ---- the next block's tile: scale, shift, ReLU, 16-byte stores as the 3x3
+                    // layer alone would make them
+                    const float* s1p = ssl1 + k4;
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) {
+                        const int oy = tl.y0 + cw * MT + mt, ox = tl.x0 + lr;
+                        const bool ok = oy < p.H && ox < p.W;
+                        char* zp = ok ? reinterpret_cast<char*>(p.z) +
+                                            ((((long)tl.b * p.H + oy) * p.W + ox) * 128 + chb)
+                                      : reinterpret_cast<char*>(g_pc_sink) + lane * 16;
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            const f32x4 sc0 = *reinterpret_cast<const f32x4*>(s1p + 32 * j);
+                            const f32x4 sh0 = *reinterpret_cast<const f32x4*>(s1p + 64 + 32 * j);
+                            const f32x4 sc1 = *reinterpret_cast<const f32x4*>(s1p + 32 * j + 16);
+                            const f32x4 sh1 = *reinterpret_cast<const f32x4*>(s1p + 64 + 32 * j + 16);
+                            const f32x4 c0 = acc1[2 * j][mt], c1 = acc1[2 * j + 1][mt];
+                            const uint32_t x0 = pc_act_pack(c0.x, c0.y, sc0.x, sc0.y, sh0.x, sh0.y, true, 1);
+                            const uint32_t x1 = pc_act_pack(c0.z, c0.w, sc0.z, sc0.w, sh0.z, sh0.w, true, 1);
+                            const uint32_t y0 = pc_act_pack(c1.x, c1.y, sc1.x, sc1.y, sh1.x, sh1.y, true, 1);
+                            const uint32_t y1 = pc_act_pack(c1.z, c1.w, sc1.z, sc1.w, sh1.z, sh1.w, true, 1);
+                            const pc_u32x2 s0 = __builtin_amdgcn_permlane16_swap(x0, y0, false, false);
+                            const pc_u32x2 s1 = __builtin_amdgcn_permlane16_swap(x1, y1, false, false);
+                            *reinterpret_cast<pc_u32x4*>(zp + j * 64) = pc_u32x4{s0.x, s1.x, s0.y, s1.y};
+                        }
+                    }
+                    // the patch was requested behind chunk QMID - 1: every store after it is counted
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NQ - QMID) * MT + 2 * MT) : "memory");
+                } else {
+                    // The patch requests are older than this tile's NQ * MT stores, every one of
+                    // which was issued (to the image or to the sink), and vector memory operations
+                    // retire in order: "all but NQ * MT" means the patch has landed.
+                    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NQ * MT) : "memory");
+                }
             } else {
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {             // channel-tile pairs (0, 1), (2, 3)
@@ -596,7 +785,9 @@ static int32_t pc_launch(const char* what, int32_t B, int32_t H, int32_t W, cons
                          const void* w, const float* scale, const float* shift, int32_t relu,
                          const void* w3, const float* scale3, const float* shift3,
                          const void* residual, const void* x0, const void* wd, const float* scaled,
-                         const float* shiftd, int pw, void* y, pe_stream_t stream) {
+                         const float* shiftd, int pw, void* y, pe_stream_t stream,
+                         const void* w1 = nullptr, const float* scale1 = nullptr,
+                         const float* shift1 = nullptr, void* z = nullptr) {
     PE_REQUIRE(x && w && y, PE_E_INVALID, "%s: NULL pointer", what);
     PE_REQUIRE(B > 0 && H > 0 && W > 0, PE_E_INVALID, "%s: sizes must be positive", what);
     PE_REQUIRE(H <= 8192 && W <= 8192, PE_E_UNSUPPORTED, "%s: images above 8192 x 8192", what);
@@ -604,7 +795,8 @@ static int32_t pc_launch(const char* what, int32_t B, int32_t H, int32_t W, cons
     PE_REQUIRE(aligned(x, 16) && aligned(w, 16) && aligned(y, 16) && aligned(scale, 16) &&
                    aligned(shift, 16) && aligned(w3, 16) && aligned(scale3, 16) &&
                    aligned(shift3, 16) && aligned(residual, 16) && aligned(x0, 16) &&
-                   aligned(wd, 16) && aligned(scaled, 16) && aligned(shiftd, 16),
+                   aligned(wd, 16) && aligned(scaled, 16) && aligned(shiftd, 16) &&
+                   aligned(w1, 16) && aligned(scale1, 16) && aligned(shift1, 16) && aligned(z, 16),
                PE_E_INVALID, "%s: tensors must be 16-byte aligned", what);
     PatchConvParams p;
     p.x = static_cast<const uint16_t*>(x);
@@ -620,10 +812,15 @@ static int32_t pc_launch(const char* what, int32_t B, int32_t H, int32_t W, cons
     p.wd = static_cast<const uint16_t*>(wd);
     p.scaled = scaled;
     p.shiftd = shiftd;
+    p.w1 = static_cast<const uint16_t*>(w1);
+    p.scale1 = scale1;
+    p.shift1 = shift1;
+    p.z = static_cast<uint16_t*>(z);
     p.B = B;
     p.H = H;
     p.W = W;
-    const int ty = pw ? PcGeo<1>::TY : PcGeo<0>::TY;
+    const int ty = pw >= 4 ? PcGeo<4>::TY : pw ? PcGeo<1>::TY : PcGeo<0>::TY;
+    static_assert(PcGeo<3>::TY == PcGeo<1>::TY, "tile heights");
     p.tiles_x = (W + PC_TX - 1) / PC_TX;
     p.tiles_y = (H + ty - 1) / ty;
     const long ntiles = (long)B * p.tiles_x * p.tiles_y;
@@ -646,6 +843,7 @@ static int32_t pc_launch(const char* what, int32_t B, int32_t H, int32_t W, cons
     else if (pw == 1 && affine && relu == 1) e = pc_launch_variant<1, true, 1>(p, nwg, st);
     else if (pw == 2 && affine && relu == 1) e = pc_launch_variant<1, true, 2>(p, nwg, st);
     else if (pw == 3 && affine && relu == 1) e = pc_launch_variant<1, true, 3>(p, nwg, st);
+    else if (pw == 4 && affine && relu == 1) e = pc_launch_variant<1, true, 4>(p, nwg, st);
     else launched = false;
     PE_REQUIRE(launched, PE_E_UNSUPPORTED,
                "%s: the fused pointwise layer needs scale / shift and ReLU on the 3x3 layer", what);
@@ -688,4 +886,22 @@ extern "C" int32_t pe_conv3x3_c64_pw_proj_fwd_bf16(int32_t B, int32_t H, int32_t
                PC_N3);
     return pc_launch(what, B, H, W, x, w, scale, shift, relu, w3, scale3, shift3, nullptr, x0, wd,
                      scaled, shiftd, 3, y, stream);
+}
+
+extern "C" int32_t pe_conv3x3_c64_pw_next_fwd_bf16(int32_t B, int32_t H, int32_t W, const void* x,
+                                                   const void* w, const float* scale,
+                                                   const float* shift, int32_t relu, const void* w3,
+                                                   int32_t Cout3, const float* scale3,
+                                                   const float* shift3, const void* residual,
+                                                   void* y, const void* w_next, int32_t Cout_next,
+                                                   const float* scale_next, const float* shift_next,
+                                                   void* y_next, pe_stream_t stream) {
+    const char* what = "pe_conv3x3_c64_pw_next_fwd_bf16";
+    PE_REQUIRE(w3 && residual && w_next && y_next, PE_E_INVALID, "%s: NULL pointer", what);
+    PE_REQUIRE(Cout3 == PC_N3, PE_E_UNSUPPORTED, "%s: the pointwise layer must have %d outputs", what,
+               PC_N3);
+    PE_REQUIRE(Cout_next == 64, PE_E_UNSUPPORTED, "%s: the next pointwise layer must have 64 outputs",
+               what);
+    return pc_launch(what, B, H, W, x, w, scale, shift, relu, w3, scale3, shift3, residual, nullptr,
+                     nullptr, nullptr, nullptr, 4, y, stream, w_next, scale_next, shift_next, y_next);
 }

@@ -35,6 +35,10 @@ from .graph import Layer, TrainGraph, Var
 BF16 = torch.bfloat16
 BN_EPS = 1e-5
 
+# The next bottleneck's conv1 inside the fused conv2 + conv3 launch of layer1
+# (pe_conv3x3_c64_pw_next_fwd_bf16).  PE_HRNET_FUSE_NEXT=0: conv1 as its own launch.
+FUSE_NEXT = os.environ.get("PE_HRNET_FUSE_NEXT", "1") != "0"
+
 
 @dataclass
 class Unit:
@@ -373,28 +377,39 @@ class PoseHRNet:
         x = pnn.stem3x3s2(x_s2d, p[u.name + ".weight"], p[u.name + ".scale"],
                           p[u.name + ".shift"], relu=1)
         x = self._unit(sp.stem[1], x)
-        for b in sp.layer1:
+        c1_out = None    # conv1 of the current block, when the previous block's launch made it
+        for bi, b in enumerate(sp.layer1):
             c2, c3 = b.c2.name, b.c3.name
             B, H, W, C = x.shape
+            have_c1, c1_out = c1_out, None
+            nxt = sp.layer1[bi + 1].c1 if bi + 1 < len(sp.layer1) else None
             fused = (b.c2.k == 3 and b.c2.stride == 1 and b.c3.k == 1 and b.c3.stride == 1
                      and pnn.c2c3_fusable(B, H, W, p[c2 + ".weight"], p[c3 + ".weight"],
                                           p[c2 + ".scale"], p[c2 + ".shift"]))
             d = b.down
             if fused and d is not None and d.k == 1 and d.stride == 1 and C == 64 and not d.relu:
                 # conv2 + conv3 + the skip path's projection + ReLU in one launch
-                x = pnn.conv3x3_c64_pw_proj(self._unit(b.c1, x), p[c2 + ".weight"], p[c2 + ".scale"],
+                o1 = have_c1 if have_c1 is not None else self._unit(b.c1, x)
+                x = pnn.conv3x3_c64_pw_proj(o1, p[c2 + ".weight"], p[c2 + ".scale"],
                                             p[c2 + ".shift"], p[c3 + ".weight"], p[c3 + ".scale"],
                                             p[c3 + ".shift"], x, p[d.name + ".weight"],
                                             p[d.name + ".scale"], p[d.name + ".shift"])
                 continue
             idn = self._unit(d, x) if d else x
-            if fused:
+            o1 = have_c1 if have_c1 is not None else self._unit(b.c1, x)
+            if (fused and FUSE_NEXT and nxt is not None and nxt.k == 1 and nxt.stride == 1
+                    and nxt.cin == 256 and nxt.cout == 64 and nxt.relu):
+                # ... and the next block's conv1 on the tile just finished
+                x, c1_out = pnn.conv3x3_c64_pw_next(
+                    o1, p[c2 + ".weight"], p[c2 + ".scale"], p[c2 + ".shift"], p[c3 + ".weight"],
+                    p[c3 + ".scale"], p[c3 + ".shift"], idn, p[nxt.name + ".weight"],
+                    p[nxt.name + ".scale"], p[nxt.name + ".shift"])
+            elif fused:
                 # conv2 + conv3 + residual + ReLU in one launch (bit-identical to the two)
-                x = pnn.conv3x3_c64_pw(self._unit(b.c1, x), p[c2 + ".weight"], p[c2 + ".scale"],
-                                       p[c2 + ".shift"], p[c3 + ".weight"], p[c3 + ".scale"],
-                                       p[c3 + ".shift"], idn, True)
+                x = pnn.conv3x3_c64_pw(o1, p[c2 + ".weight"], p[c2 + ".scale"], p[c2 + ".shift"],
+                                       p[c3 + ".weight"], p[c3 + ".scale"], p[c3 + ".shift"], idn, True)
             else:
-                x = self._unit(b.c3, self._unit(b.c2, self._unit(b.c1, x)), residual=idn, relu=True)
+                x = self._unit(b.c3, self._unit(b.c2, o1), residual=idn, relu=True)
         xs = [x]
         for tr, mods in zip(sp.transitions, sp.stages):
             xs = [(xs[i] if t is None else self._unit(t, xs[i])) if i < len(xs)

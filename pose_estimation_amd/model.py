@@ -302,6 +302,18 @@ class PoseResNet:
     # ... and, in a stage's first block, the 1x1 projection of the skip path too
     # (pe_conv3x3_c64_pw_proj_fwd_bf16).  PE_RESNET_FUSE_DOWN=0: the projection as its own launch.
     fuse_down = os.environ.get("PE_RESNET_FUSE_DOWN", "1") != "0"
+    # ... and, when another bottleneck of the stage follows, that block's conv1 (1x1 256 -> 64) on
+    # the tile just finished (pe_conv3x3_c64_pw_next_fwd_bf16): the 256-channel output is written
+    # (the next block adds it back) but not read again by a conv1 launch (403 MB at batch 256).
+    # PE_RESNET_FUSE_NEXT=0: conv1 as its own launch.
+    fuse_next = os.environ.get("PE_RESNET_FUSE_NEXT", "1") != "0"
+
+    def _next_c1_fusable(self, nxt: Optional[BlockSpec]) -> bool:
+        if not self.fuse_next or nxt is None:
+            return False
+        c = nxt.c1
+        return (c.k == 1 and c.stride == 1 and c.pad == 0 and c.cin == 256 and c.cout == 64
+                and bool(c.relu))
 
     def _c2c3_fusable(self, b: BlockSpec, x: torch.Tensor) -> bool:
         c1, c2, c3 = b.c1, b.c2, b.c3
@@ -362,6 +374,14 @@ class PoseResNet:
                 else:
                     o1 = have_c1 if have_c1 is not None else self._conv(b.c1, x)
                     idn = self._conv(b.down, x) if b.down else x
+                nxt = blocks[bi + 1] if not last else None
+                if self._next_c1_fusable(nxt):
+                    n1 = nxt.c1
+                    x, c1_out = pnn.conv3x3_c64_pw_next(
+                        o1, self.w(b.c2), self.scale[b.c2.name], self.shift[b.c2.name], self.w(b.c3),
+                        self.scale[b.c3.name], self.shift[b.c3.name], idn, self.w(n1),
+                        self.scale[n1.name], self.shift[n1.name])
+                    continue
                 x = pnn.conv3x3_c64_pw(o1, self.w(b.c2), self.scale[b.c2.name], self.shift[b.c2.name],
                                        self.w(b.c3), self.scale[b.c3.name], self.shift[b.c3.name],
                                        idn, True, **kw)

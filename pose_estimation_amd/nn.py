@@ -364,6 +364,41 @@ def conv3x3_c64_pw(x: torch.Tensor, w: torch.Tensor, scale: torch.Tensor, shift:
     return out
 
 
+def conv3x3_c64_pw_next(x: torch.Tensor, w: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor,
+                        w3: torch.Tensor, scale3, shift3, residual: torch.Tensor,
+                        w_next: torch.Tensor, scale_next, shift_next,
+                        out: Optional[torch.Tensor] = None, out_next: Optional[torch.Tensor] = None):
+    """conv3x3_c64_pw(..., relu3=True) and, in the same launch, the NEXT bottleneck's first
+    pointwise layer w_next [64,1,1,256] (+ scale_next, shift_next, ReLU) on its result
+    (pe_conv3x3_c64_pw_next_fwd_bf16).  Returns (y [B,H,W,256], y_next [B,H,W,64]); equals
+    y = conv3x3_c64_pw(...), y_next = conv2d(y, w_next, scale_next, shift_next, relu=True) bit
+    for bit."""
+    _check_act(x)
+    _need_gpu(w, scale, shift, w3, scale3, shift3, residual, w_next, scale_next, shift_next, out,
+              out_next)
+    B, H, W, C = x.shape
+    if C != 64 or tuple(w.shape) != (64, 3, 3, 64) or w.dtype != BF16 or not w.is_contiguous():
+        raise ValueError("conv3x3_c64_pw_next expects x [...,64] and w contiguous bfloat16 [64,3,3,64]")
+    N3 = w3.shape[0]
+    if w3.numel() != N3 * 64 or w3.dtype != BF16 or not w3.is_contiguous():
+        raise ValueError("w3 must be contiguous bfloat16 [Cout3,1,1,64]")
+    N1 = w_next.shape[0]
+    if w_next.numel() != N1 * N3 or w_next.dtype != BF16 or not w_next.is_contiguous():
+        raise ValueError("w_next must be contiguous bfloat16 [Cout_next,1,1,Cout3]")
+    if tuple(residual.shape) != (B, H, W, N3) or residual.dtype != BF16 or not residual.is_contiguous():
+        raise ValueError("residual must be contiguous bfloat16 [B,H,W,Cout3]")
+    if out is None:
+        out = torch.empty((B, H, W, N3), dtype=BF16, device=x.device)
+    if out_next is None:
+        out_next = torch.empty((B, H, W, N1), dtype=BF16, device=x.device)
+    with on_device(x):
+        check(lib().pe_conv3x3_c64_pw_next_fwd_bf16(
+            B, H, W, x.data_ptr(), w.data_ptr(), _ptr(scale), _ptr(shift), 1, w3.data_ptr(), N3,
+            _ptr(scale3), _ptr(shift3), residual.data_ptr(), out.data_ptr(), w_next.data_ptr(), N1,
+            _ptr(scale_next), _ptr(shift_next), out_next.data_ptr(), _stream(x)))
+    return out, out_next
+
+
 def conv3x3_c64_pw_proj(x: torch.Tensor, w: torch.Tensor, scale: torch.Tensor, shift: torch.Tensor,
                         w3: torch.Tensor, scale3, shift3, x0: torch.Tensor, wd: torch.Tensor,
                         scaled, shiftd, out: Optional[torch.Tensor] = None) -> torch.Tensor:

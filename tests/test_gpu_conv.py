@@ -291,6 +291,48 @@ def test_conv3x3_64_channels_with_the_pointwise_layer_in_the_same_launch(case):
 
 
 @pytest.mark.parametrize("case", [(2, 64, 48), (5, 16, 16), (1, 7, 5), (3, 33, 50), (300, 16, 12)])
+def test_conv3x3_pointwise_and_the_next_blocks_pointwise_in_the_same_launch(case):
+    """pe_conv3x3_c64_pw_next_fwd_bf16 (conv2 + conv3 of a bottleneck and conv1 of the next one)
+    against the three engine launches it replaces, both outputs bit for bit; exact against the
+    oracle on integer operands."""
+    B, H, W = case
+    g = torch.Generator().manual_seed(33 + H + W)
+    x = rand_bf16((B, H, W, 64), g).to(BF16).cuda()
+    w = pnn.pack_conv_weight(rand_bf16((64, 64, 3, 3), g, (2.0 / 576) ** 0.5)).cuda()
+    w3 = pnn.pack_conv_weight(rand_bf16((256, 64, 1, 1), g, (2.0 / 64) ** 0.5)).cuda()
+    w1 = pnn.pack_conv_weight(rand_bf16((64, 256, 1, 1), g, (2.0 / 256) ** 0.5)).cuda()
+    scale = (torch.rand(64, generator=g) + 0.5).cuda()
+    shift = (torch.randn(64, generator=g) * 0.1).cuda()
+    sc3, sh3 = (torch.rand(256, generator=g) + 0.5).cuda(), (torch.randn(256, generator=g) * 0.1).cuda()
+    sc1, sh1 = (torch.rand(64, generator=g) + 0.5).cuda(), (torch.randn(64, generator=g) * 0.1).cuda()
+    res = rand_bf16((B, H, W, 256), g).to(BF16).cuda()
+    for a3, b3, a1, b1 in ((sc3, sh3, sc1, sh1), (None, None, None, None), (None, sh3, sc1, None)):
+        mid = pnn.conv2d(x, w, scale, shift, None, 1, 1, True)
+        want = pnn.conv2d(mid, w3, a3, b3, res, 1, 0, True)
+        want1 = pnn.conv2d(want, w1, a1, b1, None, 1, 0, True)
+        got, got1 = pnn.conv3x3_c64_pw_next(x, w, scale, shift, w3, a3, b3, res, w1, a1, b1)
+        assert torch.equal(got, want), (a3 is not None, b3 is not None)
+        assert torch.equal(got1, want1), (a1 is not None, b1 is not None)
+    if B <= 5:
+        xi = int_tensor((B, H, W, 64), g, -2, 2)
+        wi = int_tensor((64, 64, 3, 3), g, -1, 1)
+        w3i = int_tensor((256, 64, 1, 1), g, -1, 1)
+        w1i = int_tensor((64, 256, 1, 1), g, -1, 1)
+        ri = int_tensor((B, H, W, 256), g, -3, 3)
+        one = torch.ones(64).cuda()
+        zero = torch.zeros(64).cuda()
+        mid = torch.relu(to.bf16r(to.conv2d(xi, wi, stride=1, pad=1)))
+        ref = to.bf16r(torch.relu(to.conv2d(mid, w3i, stride=1, pad=0) + ri))
+        ref1 = to.bf16r(torch.relu(to.conv2d(ref, w1i, stride=1, pad=0)))
+        goti, got1i = pnn.conv3x3_c64_pw_next(
+            xi.to(BF16).cuda(), pnn.pack_conv_weight(wi).cuda(), one, zero,
+            pnn.pack_conv_weight(w3i).cuda(), None, None, ri.to(BF16).cuda(),
+            pnn.pack_conv_weight(w1i).cuda(), None, None)
+        assert torch.equal(goti.float().cpu(), ref)
+        assert torch.equal(got1i.float().cpu(), ref1)
+
+
+@pytest.mark.parametrize("case", [(2, 64, 48), (5, 16, 16), (1, 7, 5), (3, 33, 50), (300, 16, 12)])
 def test_conv3x3_pointwise_with_the_projected_residual_in_the_same_launch(case):
     """pe_conv3x3_c64_pw_proj_fwd_bf16 (conv2 + conv3 + the projection of the skip path of a
     stage's first bottleneck) against the three engine launches it replaces, bit for bit."""

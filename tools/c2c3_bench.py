@@ -27,7 +27,17 @@ def proj(i): pnn.conv3x3_c64_pw_proj(x, w, s, h, w3, s3, h3, x0, wd, s3, h3, out
 def sep_proj(i):
     pnn.conv2d(x0, wd, s3, h3, None, 1, 0, False, out=res[i & 1])
     fused(i)
-for name, fn in (("fused", fused), ("separate", sep), ("fused", fused), ("separate", sep),
+w1 = (torch.randn((64, 1, 1, 256), generator=g) * 0.09).to(BF16).cuda()
+nxt = torch.empty((B, H, W, 64), dtype=BF16).cuda()
+def fused_next(i):
+    pnn.conv3x3_c64_pw_next(x, w, s, h, w3, s3, h3, res[i & 1], w1, s, h, out=outs[i & 1], out_next=nxt)
+def fused_then_next(i):
+    fused(i)
+    pnn.conv2d(outs[i & 1], w1, s, h, None, 1, 0, True, out=nxt)
+cases = (("fused+next conv1", fused_next), ("fused+next conv1", fused_next)) if "--next" in sys.argv else None
+for name, fn in cases or (("fused+next conv1", fused_next), ("fused, then next conv1", fused_then_next),
+                 ("fused+next conv1", fused_next), ("fused, then next conv1", fused_then_next),
+                 ("fused", fused), ("separate", sep), ("fused", fused), ("separate", sep),
                  ("fused+projection", proj), ("projection, then fused", sep_proj),
                  ("fused+projection", proj), ("projection, then fused", sep_proj)):
     for i in range(5): fn(i)
