@@ -292,11 +292,13 @@ __global__ __launch_bounds__(512, 1) void conv3x3_c64_kernel(const PatchConvPara
     constexpr int NQ = PC_N3 / 32;                        // chunks of 32 output channels
     constexpr int QMID = 2;                               // NEXT: chunks finished before the shared
                                                           // buffer is asked for again
-    pc_u32x4 R[(PW && !PROJ) ? NQ : 1][MT];
+    // (PROJ: the projection's output for the tile, worked out by the multiplying group behind
+    // its multiply, see there)
+    pc_u32x4 R[PW ? NQ : 1][MT];
     // projected residual (PW 3): the block input's pixels of the tile as an MFMA operand, and
     // three 32-channel chunks of the projection's weights at a time (chunk q in slot q % 3; a
     // slot is refilled with chunk q + 3 as soon as chunk q has been multiplied)
-    constexpr int ADS = 3;
+    constexpr int ADS = 2;
     pc_u32x4 Bx[PROJ ? MT : 1][2], AD[PROJ ? ADS : 1][2][2];
     const int wdo = (lr * 64 + kc * 8) * 2;               // this lane's byte offset in a 16-row block of wd
     auto load_ad = [&](int q) {
@@ -319,12 +321,14 @@ __global__ __launch_bounds__(512, 1) void conv3x3_c64_kernel(const PatchConvPara
             if (f < n) {
                 if constexpr (PROJ) {
                     const PcTile tm = pc_tile<G::TY>(p, blockIdx.x + f * gridDim.x);
+                    int k16 = kc * 16;                    // (opaque: worked out here, not kept)
+                    asm volatile("" : "+v"(k16));
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt) {
                         const int oy = tm.y0 + cw * MT + mt, ox = tm.x0 + lr;
                         const int cy = oy < p.H ? oy : p.H - 1, cx = ox < p.W ? ox : p.W - 1;
                         const char* xp = reinterpret_cast<const char*>(p.x0) +
-                                         (((long)tm.b * p.H + cy) * p.W + cx) * 128 + kc * 16;
+                                         (((long)tm.b * p.H + cy) * p.W + cx) * 128 + k16;
                         Bx[mt][0] = *reinterpret_cast<const pc_u32x4*>(xp);
                         Bx[mt][1] = *reinterpret_cast<const pc_u32x4*>(xp + 64);
                     }
@@ -432,6 +436,54 @@ __global__ __launch_bounds__(512, 1) void conv3x3_c64_kernel(const PatchConvPara
                 __builtin_amdgcn_s_barrier();             // the shared buffer is free from here
                 asm volatile("" ::: "memory");
             }
+            if constexpr (PROJ) {
+                // The projection of the skip path for the tile just multiplied, while this group
+                // would otherwise wait for the other one: rounded to bf16 as its own launch
+                // would store it and kept in registers until this group finishes the tile, a
+                // phase later.  (Inside the chunk loop of the finishing phase the weight chunks
+                // would queue behind that phase's stores: vector memory operations retire in
+                // order.)
+                if (f < n) {
+                    int k4 = kc * 4;
+                    asm volatile("" : "+v"(k4));
+                    const float* sdp = ssld + k4;
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) {
+                        f32x4 cd[2][MT];
+#pragma unroll
+                        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                            for (int mt = 0; mt < MT; ++mt) cd[nt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                                for (int mt = 0; mt < MT; ++mt)
+                                    cd[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                                        __builtin_bit_cast(pc_bf16x8, AD[q % ADS][nt][kk]),
+                                        __builtin_bit_cast(pc_bf16x8, Bx[mt][kk]), cd[nt][mt], 0, 0, 0);
+                        // the slot's next chunk, behind fences so that it stays here
+                        asm volatile("" ::: "memory");
+                        if (q + ADS < NQ) load_ad(q + ADS);
+                        asm volatile("" ::: "memory");
+                        // scale, shift, no ReLU
+                        const f32x4 d0 = *reinterpret_cast<const f32x4*>(sdp + q * 32);
+                        const f32x4 e0 = *reinterpret_cast<const f32x4*>(sdp + PC_N3 + q * 32);
+                        const f32x4 d1 = *reinterpret_cast<const f32x4*>(sdp + q * 32 + 16);
+                        const f32x4 e1 = *reinterpret_cast<const f32x4*>(sdp + PC_N3 + q * 32 + 16);
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt) {
+                            const f32x4 a = cd[0][mt], b = cd[1][mt];
+                            R[q][mt] = pc_u32x4{
+                                pack_bf16x2_bits(fmaf(a.x, d0.x, e0.x), fmaf(a.y, d0.y, e0.y)),
+                                pack_bf16x2_bits(fmaf(a.z, d0.z, e0.z), fmaf(a.w, d0.w, e0.w)),
+                                pack_bf16x2_bits(fmaf(b.x, d1.x, e1.x), fmaf(b.y, d1.y, e1.y)),
+                                pack_bf16x2_bits(fmaf(b.z, d1.z, e1.z), fmaf(b.w, d1.w, e1.w))};
+                        }
+                    }
+                }
+            }
         } else if (NEXT && f == 0) {
             // shared buffer: this group's first patch, behind the other group's first multiply
             __builtin_amdgcn_s_barrier();
@@ -452,12 +504,12 @@ __global__ __launch_bounds__(512, 1) void conv3x3_c64_kernel(const PatchConvPara
                 // address is kept in a register.  An offset, not a pointer: the pointer must
                 // stay visibly an LDS one, or the reads become flat loads that cannot be
                 // waited for by count.)
-                int k4 = kc * 4, a3o0 = aoff, a3o1 = aoff ^ 64;
-                asm volatile("" : "+v"(k4), "+v"(a3o0), "+v"(a3o1));
+                int ln = lane;                            // worked out again here, from the lane
+                asm volatile("" : "+v"(ln));              // number alone, instead of being kept
+                const int lr_ = ln & 15, kc_ = ln >> 4;
+                const int k4 = kc_ * 4;
+                const int a3o0 = lr_ * 128 + ((kc_ ^ (lr_ & 7)) << 4), a3o1 = a3o0 ^ 64;
                 const float* s2p = ssl + k4;
-                const float* s3p = ssl3 + k4;
-                const float* sdp = ssld + k4;
-                const char* a3p[2] = {w3l + a3o0, w3l + a3o1};   // the two 32-channel halves
                 uint32_t P[4][MT][2];
 #pragma unroll
                 for (int a = 0; a < 4; ++a) {
@@ -492,12 +544,14 @@ __global__ __launch_bounds__(512, 1) void conv3x3_c64_kernel(const PatchConvPara
                 // offset from it (q * 64 bytes).  A pixel outside the image stores to a sink: an
                 // unconditional store keeps the queue countable.
                 char* yp[MT];
+                int chbo = chb;                           // (opaque: not folded into a kept address)
+                asm volatile("" : "+v"(chbo));
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
                     const int oy = tl.y0 + cw * MT + mt, ox = tl.x0 + lr;
                     const bool ok = oy < p.H && ox < p.W;
                     yp[mt] = ok ? reinterpret_cast<char*>(p.y) +
-                                      ((((long)tl.b * p.H + oy) * p.W + ox) * (PC_N3 * 2) + chb)
+                                      ((((long)tl.b * p.H + oy) * p.W + ox) * (PC_N3 * 2) + chbo)
                                 : reinterpret_cast<char*>(g_pc_sink) + lane * 16;
                 }
                 f32x4 acc1[4][MT];                        // the next block's 64-channel tile (NEXT)
@@ -507,21 +561,18 @@ __global__ __launch_bounds__(512, 1) void conv3x3_c64_kernel(const PatchConvPara
 #pragma unroll
                         for (int mt = 0; mt < MT; ++mt) acc1[nt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
                 }
-                // NEXT: one wave per SIMD works through the chunks, so an LDS round trip it
-                // waits for is lost time.  What chunk q + 1 reads from LDS (pointwise weights,
-                // scale / shift rows, the next layer's weights: 12 reads) is requested at the
-                // top of chunk q into a second set of registers and waited for at the top of
-                // chunk q + 1, when nothing younger is in the queue.  Inline assembly, for the
-                // reason given at the K loop.
-                constexpr bool PFT = NEXT;
-                pc_u32x4 LA3[NEXT ? 2 : 1][2][2], LT[PFT ? 2 : 1][4], LA1[NEXT ? 2 : 1][4];
-                uint32_t a3b[2], tb, a1b;
-                if constexpr (NEXT) {
-                    a3b[0] = lds_w + PC_WBYTES + a3o0;
-                    a3b[1] = lds_w + PC_WBYTES + a3o1;
-                    tb = (uint32_t)(uintptr_t)(pc_lptr_t)ssl3 + k4 * 4;
-                    a1b = (uint32_t)(uintptr_t)(pc_lptr_t)w1l + (lr * 64) + ((kc ^ ((lr >> 1) & 3)) << 4);
-                }
+                // One wave per SIMD works through the chunks, so an LDS round trip it waits
+                // for is lost time.  What chunk q + 1 reads from LDS (pointwise weights, scale /
+                // shift rows, the next layer's weights: 8 or 12 reads) is requested at the top
+                // of chunk q into a second set of registers and waited for at the top of chunk
+                // q + 1, when nothing younger is in the queue.  Inline assembly, for the reason
+                // given at the K loop.
+                pc_u32x4 LA3[2][2][2], LT[2][4], LA1[NEXT ? 2 : 1][4];
+                const uint32_t a3b[2] = {lds_w + PC_WBYTES + a3o0, lds_w + PC_WBYTES + a3o1};
+                const uint32_t tb = (uint32_t)(uintptr_t)(pc_lptr_t)ssl3 + k4 * 4;
+                uint32_t a1b = 0;
+                if constexpr (NEXT)
+                    a1b = (uint32_t)(uintptr_t)(pc_lptr_t)w1l + (lr_ * 64) + ((kc_ ^ ((lr_ >> 1) & 3)) << 4);
                 auto load_chunk = [&](int q, pc_u32x4(&A3)[2][2], pc_u32x4(&T)[4], pc_u32x4(&A1)[4]) {
 #pragma unroll
                     for (int nt = 0; nt < 2; ++nt)
@@ -529,57 +580,45 @@ __global__ __launch_bounds__(512, 1) void conv3x3_c64_kernel(const PatchConvPara
                         for (int kk = 0; kk < 2; ++kk)
                             asm volatile("ds_read_b128 %0, %1 offset:%2"
                                          : "=v"(A3[nt][kk]) : "v"(a3b[kk]), "n"((q * 32 + nt * 16) * 128));
-                    if constexpr (PFT) {
-                        // scale, shift of channel tile 2 q, then of tile 2 q + 1
-                        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(T[0]) : "v"(tb), "n"(q * 128));
-                        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(T[1]) : "v"(tb), "n"(PC_N3 * 4 + q * 128));
-                        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(T[2]) : "v"(tb), "n"(q * 128 + 64));
-                        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(T[3]) : "v"(tb), "n"(PC_N3 * 4 + q * 128 + 64));
-                    }
+                    // scale, shift of channel tile 2 q, then of tile 2 q + 1
+                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(T[0]) : "v"(tb), "n"(q * 128));
+                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(T[1]) : "v"(tb), "n"(PC_N3 * 4 + q * 128));
+                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(T[2]) : "v"(tb), "n"(q * 128 + 64));
+                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(T[3]) : "v"(tb), "n"(PC_N3 * 4 + q * 128 + 64));
+                    if constexpr (NEXT) {
 #pragma unroll
-                    for (int nt = 0; nt < 4; ++nt)
-                        asm volatile("ds_read_b128 %0, %1 offset:%2"
-                                     : "=v"(A1[nt]) : "v"(a1b), "n"(q * 4096 + nt * 1024));
+                        for (int nt = 0; nt < 4; ++nt)
+                            asm volatile("ds_read_b128 %0, %1 offset:%2"
+                                         : "=v"(A1[nt]) : "v"(a1b), "n"(q * 4096 + nt * 1024));
+                    }
                 };
-                if constexpr (NEXT) load_chunk(0, LA3[0], LT[0], LA1[0]);
-                constexpr int TS = PFT ? 1 : 0;           // LT's slot mask
-
+                load_chunk(0, LA3[0], LT[0], LA1[0]);
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) {
-                    const int cur = NEXT ? (q & 1) : 0;
+                    const int cur = q & 1, c1s = NEXT ? cur : 0;
+                    if constexpr (NEXT)
+                        asm volatile("s_waitcnt lgkmcnt(0)"
+                                     : "+v"(LA3[cur][0][0]), "+v"(LA3[cur][0][1]), "+v"(LA3[cur][1][0]),
+                                       "+v"(LA3[cur][1][1]), "+v"(LT[cur][0]), "+v"(LT[cur][1]),
+                                       "+v"(LT[cur][2]), "+v"(LT[cur][3]), "+v"(LA1[cur][0]),
+                                       "+v"(LA1[cur][1]), "+v"(LA1[cur][2]), "+v"(LA1[cur][3]));
+                    else
+                        asm volatile("s_waitcnt lgkmcnt(0)"
+                                     : "+v"(LA3[cur][0][0]), "+v"(LA3[cur][0][1]), "+v"(LA3[cur][1][0]),
+                                       "+v"(LA3[cur][1][1]), "+v"(LT[cur][0]), "+v"(LT[cur][1]),
+                                       "+v"(LT[cur][2]), "+v"(LT[cur][3]));
                     if constexpr (NEXT) {
-                        if constexpr (PFT)
-                            asm volatile("s_waitcnt lgkmcnt(0)"
-                                         : "+v"(LA3[cur][0][0]), "+v"(LA3[cur][0][1]), "+v"(LA3[cur][1][0]),
-                                           "+v"(LA3[cur][1][1]), "+v"(LT[cur][0]), "+v"(LT[cur][1]),
-                                           "+v"(LT[cur][2]), "+v"(LT[cur][3]), "+v"(LA1[cur][0]),
-                                           "+v"(LA1[cur][1]), "+v"(LA1[cur][2]), "+v"(LA1[cur][3]));
-                        else
-                            asm volatile("s_waitcnt lgkmcnt(0)"
-                                         : "+v"(LA3[cur][0][0]), "+v"(LA3[cur][0][1]), "+v"(LA3[cur][1][0]),
-                                           "+v"(LA3[cur][1][1]), "+v"(LA1[cur][0]), "+v"(LA1[cur][1]),
-                                           "+v"(LA1[cur][2]), "+v"(LA1[cur][3]));
                         if (q == QMID) {
                             // the other group has finished reading the shared patch buffer
                             __builtin_amdgcn_s_barrier();
                             asm volatile("" ::: "memory");
                             issue_patch(blockIdx.x + (f + 1) * gridDim.x);
                         }
-                        if (q + 1 < NQ)
-                            load_chunk(q + 1, LA3[(q + 1) & 1], LT[(q + 1) & TS], LA1[(q + 1) & 1]);
                     }
-                    // the chunk's weights: rows 32 q .. + 31 of the pointwise filter, from LDS
-                    pc_u32x4 A3[2][2];
-#pragma unroll
-                    for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-                        for (int kk = 0; kk < 2; ++kk) {
-                            if constexpr (NEXT)
-                                A3[nt][kk] = LA3[cur][nt][kk];
-                            else
-                                A3[nt][kk] = *reinterpret_cast<const pc_u32x4*>(
-                                    a3p[kk] + (q * 32 + nt * 16) * 128);
-                        }
+                    if (q + 1 < NQ)
+                        load_chunk(q + 1, LA3[(q + 1) & 1], LT[(q + 1) & 1], LA1[NEXT ? (q + 1) & 1 : 0]);
+                    // the chunk's weights: rows 32 q .. + 31 of the pointwise filter
+                    pc_u32x4(&A3)[2][2] = LA3[cur];
                     f32x4 c3[2][MT];
 #pragma unroll
                     for (int nt = 0; nt < 2; ++nt)
@@ -594,38 +633,10 @@ __global__ __launch_bounds__(512, 1) void conv3x3_c64_kernel(const PatchConvPara
                                 c3[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
                                     __builtin_bit_cast(pc_bf16x8, A3[nt][kk]),
                                     __builtin_bit_cast(pc_bf16x8, Bc[mt][kk]), c3[nt][mt], 0, 0, 0);
-                    f32x4 cd[2][MT];
-                    if constexpr (PROJ) {
-#pragma unroll
-                        for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-                            for (int mt = 0; mt < MT; ++mt) cd[nt][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                        for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-                            for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-                                for (int mt = 0; mt < MT; ++mt)
-                                    cd[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                                        __builtin_bit_cast(pc_bf16x8, AD[q % ADS][nt][kk]),
-                                        __builtin_bit_cast(pc_bf16x8, Bx[mt][kk]), cd[nt][mt], 0, 0, 0);
-                        // the slot's next chunk, behind fences so that it stays here
-                        asm volatile("" ::: "memory");
-                        if (q + ADS < NQ) load_ad(q + ADS);
-                        asm volatile("" ::: "memory");
-                    }
-                    f32x4 s0, h0, s1, h1;
-                    if constexpr (PFT) {
-                        s0 = __builtin_bit_cast(f32x4, LT[cur][0]);
-                        h0 = __builtin_bit_cast(f32x4, LT[cur][1]);
-                        s1 = __builtin_bit_cast(f32x4, LT[cur][2]);
-                        h1 = __builtin_bit_cast(f32x4, LT[cur][3]);
-                    } else {
-                        s0 = *reinterpret_cast<const f32x4*>(s3p + q * 32);
-                        h0 = *reinterpret_cast<const f32x4*>(s3p + PC_N3 + q * 32);
-                        s1 = *reinterpret_cast<const f32x4*>(s3p + q * 32 + 16);
-                        h1 = *reinterpret_cast<const f32x4*>(s3p + PC_N3 + q * 32 + 16);
-                    }
+                    const f32x4 s0 = __builtin_bit_cast(f32x4, LT[cur][0]);
+                    const f32x4 h0 = __builtin_bit_cast(f32x4, LT[cur][1]);
+                    const f32x4 s1 = __builtin_bit_cast(f32x4, LT[cur][2]);
+                    const f32x4 h1 = __builtin_bit_cast(f32x4, LT[cur][3]);
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt) {
                         // The residual arrives as 8 contiguous channels per lane; the same row
@@ -634,17 +645,12 @@ __global__ __launch_bounds__(512, 1) void conv3x3_c64_kernel(const PatchConvPara
                         // the swaps right behind the load, chunks early, and wait for it there.)
                         uint32_t ru[4];                 // residual: channel tile 2q (2 words), 2q+1 (2)
                         if constexpr (PROJ) {
-                            // the projection's output as its own launch would have stored it:
-                            // scale, shift, no ReLU, rounded to bf16
-                            const f32x4 d0 = *reinterpret_cast<const f32x4*>(sdp + q * 32);
-                            const f32x4 e0 = *reinterpret_cast<const f32x4*>(sdp + PC_N3 + q * 32);
-                            const f32x4 d1 = *reinterpret_cast<const f32x4*>(sdp + q * 32 + 16);
-                            const f32x4 e1 = *reinterpret_cast<const f32x4*>(sdp + PC_N3 + q * 32 + 16);
-                            const f32x4 a = cd[0][mt], b = cd[1][mt];
-                            ru[0] = pack_bf16x2_bits(fmaf(a.x, d0.x, e0.x), fmaf(a.y, d0.y, e0.y));
-                            ru[1] = pack_bf16x2_bits(fmaf(a.z, d0.z, e0.z), fmaf(a.w, d0.w, e0.w));
-                            ru[2] = pack_bf16x2_bits(fmaf(b.x, d1.x, e1.x), fmaf(b.y, d1.y, e1.y));
-                            ru[3] = pack_bf16x2_bits(fmaf(b.z, d1.z, e1.z), fmaf(b.w, d1.w, e1.w));
+                            pc_u32x4 r = R[q][mt];
+                            asm volatile("" : "+v"(r));
+                            ru[0] = r.x;
+                            ru[1] = r.y;
+                            ru[2] = r.z;
+                            ru[3] = r.w;
                         } else {
                             pc_u32x4 r = R[q][mt];
                             asm volatile("" : "+v"(r));
@@ -689,7 +695,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_c64_kernel(const PatchConvPara
 #pragma unroll
                             for (int nt = 0; nt < 4; ++nt)
                                 acc1[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                                    __builtin_bit_cast(pc_bf16x8, LA1[cur][nt]),
+                                    __builtin_bit_cast(pc_bf16x8, LA1[c1s][nt]),
                                     __builtin_bit_cast(pc_bf16x8, Bn), acc1[nt][mt], 0, 0, 0);
                         }
                     }
