@@ -30,12 +30,22 @@ def main():
     stem, blocks, deconvs, final = pm.resnet50_pose_specs()
     # a launch may cover several layers: conv2 + conv3 (+ the projection of the skip path) of
     # the bottlenecks whose 3x3 layer has 64 channels go through one fused launch
+    # ... and, behind a block without a projection, the next block's conv1 (256 -> 64) as well
     seq = [("stem", ["stem"])]
-    for b in blocks:
+    have_c1 = False
+    for i, b in enumerate(blocks):
         if b.c2.cin == 64 and b.c2.cout == 64 and b.c2.stride == 1:
             group = [b.c2.name, b.c3.name] + ([b.down.name] if b.down else [])
-            seq += [(b.c1.name, [b.c1.name]),
-                    (b.c2.name.replace("conv2", "conv2+3") + ("+down" if b.down else ""), group)]
+            label = b.c2.name.replace("conv2", "conv2+3") + ("+down" if b.down else "")
+            if not have_c1:
+                seq.append((b.c1.name, [b.c1.name]))
+            nxt = blocks[i + 1].c1 if i + 1 < len(blocks) else None
+            have_c1 = (b.down is None and nxt is not None and nxt.k == 1 and nxt.stride == 1
+                       and nxt.cin == 256 and nxt.cout == 64)
+            if have_c1:
+                group.append(nxt.name)
+                label += "+next conv1"
+            seq.append((label, group))
         else:
             seq += [(n, [n]) for n in [b.c1.name, b.c2.name] + ([b.down.name] if b.down else [])
                     + [b.c3.name]]
@@ -50,7 +60,7 @@ def main():
         wgs = int(r["Grid_Size_X"]) // 256 * int(r["Grid_Size_Y"])
         kn = r["Kernel_Name"]
         kern = kn.split("<")[1].split(">")[0] if "<" in kn else kn.split("(")[0].replace("pe::", "")
-        print(f"{name:22s} tile {kern:8s} wgs {wgs:6d} {dur:8.1f} us {tf:7.1f} TF/s")
+        print(f"{name:34s} tile {kern:8s} wgs {wgs:6d} {dur:8.1f} us {tf:7.1f} TF/s")
     print(f"layer kernels total {tot:.1f} us (the stem's row includes the max pool when the two are "
           "one launch)")
 

@@ -29,17 +29,29 @@ def layer_bytes(batch, H=256, W=192):
     out.append(("stem+pool", batch * (h * w * 16 + (h // 2) * (w // 2) * stem.cout) * 2
                 + stem.cout * 4 * 64 * 2))
     h, w = h // 2, w // 2
-    for b in blocks:
+    have_c1 = False
+    for i, b in enumerate(blocks):
         s = b.c2.stride
         ho, wo = h // s, w // s
-        out.append((b.c1.name, batch * h * w * (b.c1.cin + b.c1.cout) * 2 + b.c1.cin * b.c1.cout * 2))
+        if not have_c1:
+            out.append((b.c1.name, batch * h * w * (b.c1.cin + b.c1.cout) * 2 + b.c1.cin * b.c1.cout * 2))
+        have_c1 = False
         if b.c2.cin == 64 and b.c2.cout == 64 and s == 1:
             # conv2 + conv3 (+ the projection of the skip path) are one launch: conv2's input,
-            # the residual (or the projection's 64-channel input), the output, the weights
+            # the residual (or the projection's 64-channel input), the output, the weights;
+            # behind a block without a projection the launch also holds the next block's conv1
+            # (its 64-channel output and its weights on top)
             wts = (9 * 64 * 64 + 64 * b.c3.cout + (b.down.cin * b.down.cout if b.down else 0)) * 2
             res = b.down.cin if b.down else b.c3.cout
-            out.append((b.c2.name.replace("conv2", "conv2+3") + ("+down" if b.down else ""),
-                        batch * h * w * (64 + res + b.c3.cout) * 2 + wts))
+            label = b.c2.name.replace("conv2", "conv2+3") + ("+down" if b.down else "")
+            nxt = blocks[i + 1].c1 if i + 1 < len(blocks) else None
+            have_c1 = (b.down is None and nxt is not None and nxt.k == 1 and nxt.stride == 1
+                       and nxt.cin == 256 and nxt.cout == 64)
+            extra = 0
+            if have_c1:
+                label += "+next conv1"
+                extra = batch * h * w * nxt.cout * 2 + nxt.cin * nxt.cout * 2
+            out.append((label, batch * h * w * (64 + res + b.c3.cout) * 2 + wts + extra))
             continue
         out.append((b.c2.name, batch * (h * w * b.c2.cin + ho * wo * b.c2.cout) * 2
                     + 9 * b.c2.cin * b.c2.cout * 2))
@@ -85,7 +97,7 @@ def main():
     tfile = ROOT / "profiles" / "traffic.json"
     data = json.loads(tfile.read_text())
     data[f"resnet50_pose_infer_256x192_b{batch}_bf16"] = {
-        "kernel": "igemm_kernel (sum over the conv/deconv launches of one forward)",
+        "kernel": "igemm_kernel + stem_pool_kernel + conv3x3_c64_kernel (sum over the conv/deconv launches of one forward)",
         "command": "PE_RESNET_DOWN_STREAM=0 tools/collect_traffic.sh infer; tools/infer_traffic_table.py",
         "correction": "read bytes = 2 x FETCH_SIZE x 1024 (gfx950), written = WRITE_SIZE x 1024",
         "traffic_bytes_per_launch": int(tot_m),
