@@ -355,7 +355,7 @@ int32_t pe_conv3x3_c64_fwd_bf16(int32_t B, int32_t H, int32_t W, const void* x, 
 /* The 32-channel twin: 3x3 stride-1 pad-1 conv with 32 input and 32 output channels (+ scale,
  * shift, residual, relu as in pe_conv2d_fwd_bf16), x, residual, y [B,H,W,32] bf16 NHWC, w in
  * the narrow packing [32][3][2][64] that pe_conv2d_fwd_bf16 takes for 32 input channels: the
- * 3x3 layers of the highest-resolution branch of a multi-branch backbone (nets/*.py,
+ * 3x3 layers of the highest-resolution branch of a multi-branch backbone (the files under nets/,
  * PoseEstimation.pyproj:31-32; absent) for inference.  Persistent workgroups with the whole
  * filter in LDS (60 KB per workgroup: they share a CU with other launches).  H, W <= 8192.
  * Equals pe_conv2d_fwd_bf16 on the same operands bit for bit. */
